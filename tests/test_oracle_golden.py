@@ -1,0 +1,97 @@
+"""Pin the oracle: the dense CPU restatement must reproduce what the REAL
+reference (trainers/rpo.py CustomCLIP, imported by tools/make_golden.py in the
+build container) produced on the same generated weights / inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rpo_oracle
+from rpo_amd import synth
+from rpo_amd.config import flops_image, flops_text, vit_b16, vit_l14
+
+from helpers import CASES, load_golden, oracle_for, workload
+
+FAST = ["d1_k4_b2", "d2_k8_b3", "d2_k24_b2_init", "d2_k48_b2"]
+
+
+def test_tokens_fixture_matches_survey():
+    toks = synth.oxford_pets_base_tokens()
+    assert toks.shape == (19, 77)
+    assert synth.len_prompts(toks).tolist() == [10, 10, 14, 11, 8, 8, 9, 8, 8, 11, 8, 10, 13, 10, 11, 10, 10, 10, 10]
+    assert (toks[:, 0] == 49406).all()
+    for c, n in enumerate(synth.len_prompts(toks)):
+        assert toks[c, n - 1] == 49407 and (toks[c, n:] == 0).all()
+
+
+def test_generator_is_stable():
+    """Fixtures store a checksum of the generated weights: generator drift (numpy
+    upgrade, edited stds) would silently unpin every golden otherwise."""
+    for tag in ("d1_k4_b2",):
+        cfg, sd, *_ = workload(tag)
+        assert synth.state_dict_checksum(sd) == load_golden(tag)["weights_crc"].item().decode()
+
+
+def test_sparse_token_table_matches_full():
+    cfg = vit_b16(layers_v=0, layers_t=0)
+    rows = [0, 5, 1023, 1024, 49406, 49407]
+    full = synth.clip_state_dict(cfg)["token_embedding.weight"]
+    sparse = synth.clip_state_dict(cfg, token_rows=rows)["token_embedding.weight"]
+    assert np.array_equal(full[rows], sparse[rows])
+
+
+@pytest.mark.parametrize("tag", FAST + ["d12_k24_b4"])
+def test_dense_oracle_matches_reference(tag):
+    g = load_golden(tag)
+    m, image, label = oracle_for(tag)
+    with torch.no_grad():
+        logits = m.forward(image).logits
+    # fp32 noise floor of the reference itself is ~4e-6 on logits
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-5, rtol=0)
+    out, gt, gi = m.loss_and_grads(image, label)
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-5
+    for mine, ref in ((gt.numpy(), g["g_text"]), (gi.numpy(), g["g_img"])):
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_prompt_rows_per_block():
+    g = load_golden("d2_k8_b3")
+    m, image, label = oracle_for("d2_k8_b3")
+    with torch.no_grad():
+        _, trows = m.text_tower(m.text_prompt, return_rows=True)
+        _, irows = m.image_tower(torch.from_numpy(image), m.img_prompt, return_rows=True)
+    np.testing.assert_allclose(torch.stack(trows).numpy(), g["text_rows"], atol=2e-5)
+    np.testing.assert_allclose(torch.stack(irows).numpy(), g["img_rows"], atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["d2_k8_b3", "d12_k24_b4"])
+def test_sgd_steps_match_reference(tag):
+    g = load_golden(tag)
+    cfg, sd, toks, tp, ip, _, _ = workload(tag)
+    depth, K, B, _ = CASES[tag]
+    m, _, _ = oracle_for(tag)
+    lr, mom, wd = g["sgd_hparams"]
+    opt = rpo_oracle.OracleSGD(lr, mom, wd)
+    losses = []
+    for step in range(4):
+        im = synth.images(cfg, B, seed=1234 + 10 * step)
+        lb = synth.labels(cfg, B, seed=4321 + 10 * step)
+        losses += rpo_oracle.train_steps(m, opt, [(im, lb)])
+        if step in (0, 3):
+            np.testing.assert_allclose(m.text_prompt.detach().numpy(), g[f"text_prompt_step{step + 1}"], atol=2e-6)
+            np.testing.assert_allclose(m.img_prompt.detach().numpy(), g[f"img_prompt_step{step + 1}"], atol=2e-6)
+    np.testing.assert_allclose(losses, g["sgd_losses"], atol=3e-5)
+
+
+def test_algorithmic_flops_match_survey():
+    """SURVEY.md section 8d quotes these to 2 decimals (GFLOP)."""
+    lens = [10, 10, 14, 11, 8, 8, 9, 8, 8, 11, 8, 10, 13, 10, 11, 10, 10, 10, 10]
+    f, b = flops_image(vit_b16())
+    assert round(f / 1e9, 2) == 38.72 and round(b / 1e9, 2) == 3.59
+    assert round(flops_text(vit_b16(), lens) / 1e9, 2) == 58.08
+    for K, fi, ft in ((4, 36.32, 9.68), (8, 37.52, 19.36), (16, 39.91, 38.72), (48, 49.49, 116.16)):
+        c = vit_b16(K=K)
+        assert round(sum(flops_image(c)) / 1e9, 2) == fi
+        assert round(flops_text(c, lens) / 1e9, 2) == ft
+    f, b = flops_image(vit_l14())
+    assert round(f / 1e9, 2) == 174.75 and round(b / 1e9, 2) == 12.72
+    assert round(flops_text(vit_l14(), lens) / 1e9, 2) == 130.51
