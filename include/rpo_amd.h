@@ -1,0 +1,186 @@
+/*
+ * rpo_amd.h -- C ABI of librpo_hip.so: the MI355X (gfx950) kernels behind RPO's
+ * few-shot train step.
+ *
+ * The reference (mlvlab/RPO) has no FFI / plugin registry: its hot path is stock
+ * torch.nn modules called from trainers/rpo.py:161-232 (CustomCLIP.forward) and
+ * clip/model.py:181-207 (ResidualAttentionBlock / Transformer).  Each entry point
+ * below replaces one stock-torch op sequence on that path; the comment on each
+ * cites the reference lines it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless noted
+ *   - the caller (PyTorch-ROCm) allocates and owns every buffer; nothing here
+ *     allocates, frees or keeps global mutable state
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as
+ *     void*; 0 = the null stream) and returns immediately
+ *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = RPO_E_* argument
+ *     error (nothing was enqueued); rpo_error_string() decodes any of them
+ *   - dtype arguments take RPO_F32 / RPO_BF16.  "act dtype" is the storage type of
+ *     activations and frozen weights: RPO_F32 = parity mode (exact-f32 MFMA,
+ *     v_mfma_f32_32x32x2_f32), RPO_BF16 = throughput mode (bf16 storage,
+ *     v_mfma_f32_32x32x16_bf16, fp32 accumulate).  The residual stream, LayerNorm
+ *     statistics, softmax, logits, loss, gradients of the prompts and the
+ *     optimiser state are fp32 in both modes.
+ *   - leading dimensions (ld*) are in ELEMENTS of the respective dtype
+ *
+ * Row layout of the image tower (B images, N = 1 + patches frozen tokens,
+ * Kp read-only prompts per image):
+ *     rows [0, B*N)          frozen tokens, image-major:  b*N + t
+ *     rows [B*N, B*N + B*Kp) prompt tokens, image-major:  B*N + b*Kp + i
+ * so the rows that are back-propagated form one contiguous sub-matrix.
+ */
+#ifndef RPO_AMD_H
+#define RPO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPO_ABI_VERSION 1
+
+enum { RPO_F32 = 0, RPO_BF16 = 1 };
+
+enum {
+  RPO_E_BADARG = -1,   /* null pointer / non-positive size */
+  RPO_E_SHAPE = -2,    /* size not supported by the kernels (see each function) */
+  RPO_E_DTYPE = -3,    /* dtype combination not supported */
+  RPO_E_ALIGN = -4     /* pointer / leading dimension not 16-byte aligned */
+};
+
+/* GEMM epilogues (fused into the MFMA kernel's store) */
+enum {
+  RPO_EPI_NONE = 0,        /* C = acc                                  (dX GEMMs of the backward)            */
+  RPO_EPI_BIAS = 1,        /* C = acc + bias[n]                        (in-proj, clip/model.py:186)          */
+  RPO_EPI_BIAS_QGELU = 2,  /* C = quickgelu(acc + bias); optionally saves u = acc + bias (fp32) for rows
+                              >= aux_row0 (the rows that will be back-propagated)   (c_fc, clip/model.py:174-175) */
+  RPO_EPI_BIAS_RESID = 3,  /* C(f32) = resid + acc + bias              (out_proj / c_proj + residual, :189-190) */
+  RPO_EPI_QGELU_BWD = 4,   /* C = acc * quickgelu'(aux[m,n])           (backward through clip/model.py:162-164) */
+  RPO_EPI_PATCH = 5        /* C(f32)[m + m/group + 1, n] = acc + resid[(m % group) + 1, n]: patch embedding
+                              written straight into the token matrix with the positional embedding added
+                              (trainers/rpo.py:198-202)                                                      */
+};
+
+typedef struct rpo_gemm_args {
+  const void* A;  int64_t lda;   /* [M, K] act dtype, row-major                                   */
+  const void* W;  int64_t ldw;   /* [N, K] act dtype, row-major (nn.Linear weight layout [out,in]) */
+  void* C;        int64_t ldc;   /* [M, N] out_dtype                                              */
+  int32_t M, N, K;
+  int32_t in_dtype, out_dtype, epilogue;
+  const float* bias;             /* [N] fp32 or NULL                                              */
+  const float* resid; int64_t ldr; /* fp32; RESID: [M, N]; PATCH: positional embedding [group+1, N] */
+  void* aux; int64_t ldaux;      /* fp32; see epilogues                                           */
+  int32_t aux_row0;              /* BIAS_QGELU: first row whose pre-activation is saved (aux row 0);
+                                    pass M (or aux = NULL) to save nothing                        */
+  int32_t skip_row0, skip_col0;  /* tiles with all rows >= skip_row0 AND all cols >= skip_col0 are not
+                                    computed (K/V of prompt rows are never read); -1 disables      */
+  int32_t group;                 /* PATCH: patches per image                                       */
+} rpo_gemm_args;
+
+int rpo_version(void);
+const char* rpo_error_string(int code);
+
+/* C = A . W^T with a fused epilogue.  Requires K % 64 == 0 (bf16) / K % 32 == 0 (f32),
+ * N % 4 == 0, 16-byte aligned rows.  Replaces nn.Linear / F.linear / the matmuls of
+ * nn.MultiheadAttention's packed in-proj and out-proj (clip/model.py:171-177,186) and,
+ * in the backward, autograd's mm(dY, W) (trainers/rpo.py:308). */
+int rpo_gemm_nt(const rpo_gemm_args* args, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta, statistics in fp32, eps as given (1e-5).
+ * x fp32 [rows, d] (ldx), y in y_dtype.  d % 4 == 0, d <= 2048.  In-place (y == x, fp32) is allowed.
+ * Replaces clip/model.py:153-159 (ln_1, ln_2, ln_pre, ln_post, ln_final). */
+int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      void* y, int64_t ldy, int y_dtype, int rows, int d, float eps, void* stream);
+
+/* dx = dres + dLN(dy; x, gamma)   (frozen affine: no dgamma/dbeta).
+ * dy in dy_dtype [rows, d]; x fp32 = the forward input; dres fp32 or NULL;
+ * dx fp32; dx_cast (optional, may be NULL) receives a copy of dx in cast_dtype
+ * (the next GEMM's A operand).  Replaces autograd through clip/model.py:158. */
+int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
+                      const float* gamma, const float* dres, int64_t lddres,
+                      float* dx, int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast,
+                      int rows, int d, float eps, void* stream);
+
+/* Non-overlapping-patch im2col: img [B,3,H,W] fp32 -> out [B*(H/p)*(W/p), ldo] act dtype, column
+ * order (c, ky, kx) = conv1.weight.reshape(d, -1); columns [3*p*p, ldo) are zero-filled.
+ * With rpo_gemm_nt(RPO_EPI_PATCH) this replaces the stride-p Conv2d at trainers/rpo.py:198-200. */
+int rpo_im2col_patches(const float* img, void* out, int out_dtype, int64_t ldo,
+                       int B, int H, int W, int patch, void* stream);
+
+/* Writes the rows the patch GEMM does not: CLS rows x[b*N] = cls + pos[0] and the prompt rows
+ * x[B*N + b*Kp + i] = img_prompt[i] (no positional embedding: trainers/rpo.py:201-204). */
+int rpo_img_assemble(float* x, int64_t ldx, const float* cls, const float* pos0,
+                     const float* img_prompt, int B, int N, int Kp, int d, void* stream);
+
+/* dst[g*rows + i, :] = src[i, :]  (text prompts written into every class, trainers/rpo.py:176-177) */
+int rpo_broadcast_rows(const float* src, float* dst, int64_t ld, int groups, int rows, int d, void* stream);
+
+/* out[i, :] = sum_g src[g*rows + i, :] in fixed order g = 0..groups-1 (autograd of .repeat()) */
+int rpo_reduce_groups(const float* src, int64_t ld, float* out, int groups, int rows, int d, void* stream);
+
+/* Read-only masked attention of the image tower, all heads (head_dim 64), all B images.
+ * q, k, v: act-dtype matrices in the row layout above with leading dimension ld (typically
+ * three column slices of one packed [R, 3d] in-proj output).  Every query row (frozen and
+ * prompt) reads ONLY the N frozen keys of its own image: the additive mask of
+ * trainers/rpo.py:154-156 is -inf on the prompt columns for all rows, so those columns are
+ * skipped, not computed.  out[R, ldo] act dtype.  N <= 288.
+ * Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (clip/model.py:186). */
+int rpo_attn_readonly_fwd(const void* q, const void* k, const void* v, int64_t ld,
+                          void* out, int64_t ldo, int dtype, int B, int H, int N, int Kp,
+                          float scale, void* stream);
+
+/* Backward of the above for the prompt rows only: dq[B*Kp, lddq] given da[B*Kp, ldda].
+ * q_rows points at the first PROMPT row of q; k, v at the first frozen row.  dK/dV are not
+ * produced: keys/values belong to frozen tokens.  Kp <= 64, N <= 288. */
+int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                          const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
+                          int B, int H, int N, int Kp, float scale, void* stream);
+
+/* Text-tower attention for `rows` query rows per class against that class's cached keys /
+ * values kc, vc [n_cls * Lmax, ldkv] (class c uses rows c*Lmax .. c*Lmax + len[c]).
+ * causal = 0: every row reads keys [0, len[c])            (prompt rows, trainers/rpo.py:146-149:
+ *             causal AND col < len_c, and prompts sit at positions >= len_c)
+ * causal = 1: row t reads keys [0, min(t + 1, len[c]))     (the one-off pass over the frozen tokens)
+ * len: int32 device array [n_cls].  Lmax <= 128. */
+int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
+                      void* out, int64_t ldo, int dtype, const int32_t* len, int n_cls, int rows,
+                      int Lmax, int H, int causal, float scale, void* stream);
+
+int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
+                      const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
+                      const int32_t* len, int n_cls, int rows, int Lmax, int H, float scale, void* stream);
+
+/* Cosine-logit head, cross-entropy and their backward (trainers/rpo.py:215-230):
+ *   logits[b,c] = (scale_exp / K) * sum_i <img_f[b,i]/|.|, text_f[c,i]/|.|>
+ *   loss = mean_b CE(logits[b], label[b])
+ * img_f [B,K,e], text_f [C,K,e], logits [B,C], loss [1], d_img_f / d_text_f like the inputs, all fp32.
+ * label: int64 device array [B], or NULL for eval (only logits are written).
+ * workspace: fp32, at least rpo_head_workspace_floats(B, C, K, e) elements. */
+int64_t rpo_head_workspace_floats(int B, int C, int K, int e);
+int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
+                     float* logits, float* loss, float* d_img_f, float* d_text_f,
+                     int B, int C, int K, int e, float* workspace, void* stream);
+
+/* torch.optim.SGD (dampening 0, no nesterov) on n fp32 scalars (trainers/rpo.py:274,309):
+ *   g' = grad_scale * g + wd * p;  buf = first ? g' : momentum * buf + g';  p -= lr * buf
+ * grad_scale = 1 / world_size after a sum all-reduce. */
+int rpo_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                 float grad_scale, int first_step, void* stream);
+
+/* fp32 -> act dtype copy with leading dimensions (weight packing at load time) */
+int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
+                int rows, int cols, void* stream);
+
+/* Hardware probe used by the test-suite: one wave runs one MFMA on index-coded operands so the
+ * fragment layouts the kernels assume can be checked on the device.  which: 0 = 32x32x16 bf16,
+ * 1 = 32x32x2 f32.  a [32, kdim], b [32, kdim] fp32 host-layout inputs (device memory),
+ * d [32,32] fp32 receives D[i][j] = sum_k a[i][k] * b[j][k] as the kernels' layout map decodes it. */
+int rpo_probe_mfma(int which, const float* a, const float* b, float* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPO_AMD_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of librpo_hip.so (include/rpo_amd.h).
+
+There is NO fallback: if the shared object is missing or a symbol cannot be
+resolved this module raises, and every op in ``rpo_amd.ops`` raises with it.
+The oracle under ``oracle/`` is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librpo_hip.so")
+
+RPO_F32, RPO_BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH = range(6)
+
+c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    """struct rpo_gemm_args (include/rpo_amd.h)."""
+    _fields_ = [
+        ("A", c_vp), ("lda", c_i64),
+        ("W", c_vp), ("ldw", c_i64),
+        ("C", c_vp), ("ldc", c_i64),
+        ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("in_dtype", c_i32), ("out_dtype", c_i32), ("epilogue", c_i32),
+        ("bias", c_vp),
+        ("resid", c_vp), ("ldr", c_i64),
+        ("aux", c_vp), ("ldaux", c_i64),
+        ("aux_row0", c_i32),
+        ("skip_row0", c_i32), ("skip_col0", c_i32),
+        ("group", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/rpo_amd.h declares
+SIGNATURES = {
+    "rpo_version": (c_i32, []),
+    "rpo_error_string": (C.c_char_p, [c_i32]),
+    "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                  c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_im2col_patches": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "rpo_img_assemble": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "rpo_broadcast_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "rpo_reduce_groups": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "rpo_attn_readonly_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                      c_f32, c_vp]),
+    "rpo_attn_readonly_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                      c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_text_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32,
+                                  c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_text_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp,
+                                  c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_head_workspace_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "rpo_head_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                 c_vp, c_vp]),
+    "rpo_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "rpo_convert": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
+    "rpo_probe_mfma": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class RPOLibraryError(RuntimeError):
+    pass
+
+
+def load(path: str | None = None):
+    """dlopen the HIP library and bind every declared symbol (fails loudly)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RPOLibraryError(
+            f"{p} not found: build it with `python -m rpo_amd.build` (hipcc, gfx950). "
+            "rpo_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RPOLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RPOLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().rpo_error_string(int(rc))
+        raise RPOLibraryError(f"{what or 'rpo call'} failed: {msg.decode() if msg else rc} (code {rc})")

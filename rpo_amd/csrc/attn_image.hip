@@ -1,0 +1,428 @@
+// Read-only masked attention of the image tower (forward for all rows, backward for the
+// prompt rows), MFMA on gfx950.
+//
+// Reference semantics: nn.MultiheadAttention with the additive mask of
+// trainers/rpo.py:154-156 -- the last K *columns* are -inf for every query row, so every
+// query (CLS, patches, prompts) reads exactly the N = 1 + patches frozen keys of its own
+// image and nothing reads a prompt.  exp(-inf) = 0 exactly, so the prompt columns are
+// skipped instead of computed-and-masked.
+//
+// One workgroup per (image, head).  K and V of the N frozen tokens are staged ONCE into
+// LDS (N <= 288, head_dim 64: <= 78 KB in bf16, <= 150 KB in f32) and every wave takes a
+// 32-query tile.  The score tile is computed transposed, S^T = K . Q^T, so that by the
+// 32x32 C/D map (col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) a lane holds ONE
+// query's scores in registers: the softmax row-reduce is an in-register reduction plus a
+// single cross-half exchange (shuffle by 32), no LDS.  P stays in registers: its
+// register->key order is taken as the contraction order of the P.V MFMAs and V is read
+// from LDS in that same order (any k-permutation applied to both operands cancels), so no
+// lane movement is needed between softmax and P.V.
+//
+// bf16: v_mfma_f32_32x32x16_bf16; K rows padded to 144 B, V stored transposed [64][Npad+4]
+//       so an A-operand fragment (8 keys for one d) is two 8-B LDS reads.
+// f32 : v_mfma_f32_32x32x2_f32 (exact f32 fma chain); one float per lane per operand, so
+//       K and V stay row-major [Npad][65].
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <typename T, int NT> struct AL;  // LDS layout
+template <int NT> struct AL<bf16_t, NT> {
+  static constexpr int NPAD = NT * 32;
+  static constexpr int KROW = 144;                 // bytes per K (or row-major V) row
+  static constexpr int TROW = (NPAD + 4) * 2;      // bytes per transposed row
+  static constexpr int K_BYTES = NPAD * KROW;
+  static constexpr int T_BYTES = 64 * TROW;
+  static constexpr int FWD_BYTES = K_BYTES + T_BYTES;           // Ks | Vt
+  static constexpr int BWD_BYTES = 2 * K_BYTES + T_BYTES;       // Ks | Vs | Kt
+};
+template <int NT> struct AL<float, NT> {
+  static constexpr int NPAD = NT * 32;
+  static constexpr int ROWF = 65;                  // floats per row
+  static constexpr int K_BYTES = NPAD * ROWF * 4;
+  static constexpr int FWD_BYTES = 2 * K_BYTES;    // Ks | Vs
+  static constexpr int BWD_BYTES = 2 * K_BYTES;
+};
+
+__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 u;
+  u[0] = pack_bf16x2(p[0], p[1]); u[1] = pack_bf16x2(p[2], p[3]);
+  u[2] = pack_bf16x2(p[4], p[5]); u[3] = pack_bf16x2(p[6], p[7]);
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ bf16x8_t join8(uint2 lo, uint2 hi) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 u;
+  u[0] = lo.x; u[1] = lo.y; u[2] = hi.x; u[3] = hi.y;
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// ---- staging ---------------------------------------------------------------------------
+// rows [0, N) of one (image, head) slice: src + key*ld + (already offset to head), 64 elems
+template <int NT, int NTHREADS>
+__device__ __forceinline__ void stage_rows_bf16(char* dst, const bf16_t* src, int64_t ld, int N, int tid) {
+  for (int id = tid; id < NT * 32 * 8; id += NTHREADS) {
+    const int key = id >> 3, c = id & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (key < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)key * ld + c * 8);
+    *reinterpret_cast<uint4*>(dst + key * 144 + c * 16) = v;
+  }
+}
+template <int NT, int NTHREADS>
+__device__ __forceinline__ void stage_transposed_bf16(char* dst, const bf16_t* src, int64_t ld, int N, int tid) {
+  constexpr int TROW = AL<bf16_t, NT>::TROW;
+  for (int id = tid; id < NT * 32 * 8; id += NTHREADS) {
+    const int key = id >> 3, c = id & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (key < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)key * ld + c * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t e = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+      *reinterpret_cast<bf16_t*>(dst + (c * 8 + j) * TROW + key * 2) = e;
+    }
+  }
+}
+template <int NT, int NTHREADS>
+__device__ __forceinline__ void stage_rows_f32(float* dst, const float* src, int64_t ld, int N, int tid) {
+  for (int id = tid; id < NT * 32 * 16; id += NTHREADS) {
+    const int key = id >> 4, c = id & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key < N) v = *reinterpret_cast<const float4*>(src + (int64_t)key * ld + c * 4);
+    float* d = dst + key * 65 + c * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+// ---- per-lane operand fragments of one 32-row tile loaded straight from global ----------
+template <typename T> struct RowFrag;
+template <> struct RowFrag<bf16_t> {
+  bf16x8_t f[4];
+  __device__ __forceinline__ void load(const bf16_t* rowp, int half) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 16 + half * 8);
+  }
+};
+template <> struct RowFrag<float> {
+  float f[32];  // element half*32 + ks
+  __device__ __forceinline__ void load(const float* rowp, int half) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(rowp + half * 32 + 4 * i);
+      f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+    }
+  }
+};
+
+// acc[t] (+)= M[32t + i][:] . frag^T  -> D[i][q], M row-major in LDS (K or V)
+template <typename T, int NT>
+__device__ __forceinline__ void rows_times_frag(const char* lds, const RowFrag<T>& fr, f32x16_t (&acc)[NT],
+                                                int l31, int half) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if constexpr (sizeof(T) == 2) {
+      const char* rowp = lds + (32 * t + l31) * 144 + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.f[ks], acc[t], 0, 0, 0);
+      }
+    } else {
+      const float* rowp = reinterpret_cast<const float*>(lds) + (32 * t + l31) * 65 + half * 32;
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[ks], fr.f[ks], acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// softmax over the keys held by this lane and its partner half (lane ^ 32); p normalised in place
+template <typename T, int NT>
+__device__ __forceinline__ void softmax_rows(f32x16_t (&acc)[NT], int N, int half, float scale) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+      acc[t][r] = key < N ? acc[t][r] * scale : -INFINITY;
+      m = fmaxf(m, acc[t][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e;
+      if constexpr (sizeof(T) == 2) e = exp2f((acc[t][r] - m) * LOG2E);
+      else e = expf(acc[t][r] - m);
+      acc[t][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+}
+
+// o[dt] += Mt-contraction:  D[d][q] += sum_key M[key][d] * w[q][key], keys of tile t.
+// bf16: M stored transposed (mt, [64][NPAD+4]); f32: M row-major (ms, [NPAD][65]).
+template <typename T, int NT>
+__device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f32x16_t& w, f32x16_t (&o)[2],
+                                              int l31, int half) {
+  if constexpr (sizeof(T) == 2) {
+    constexpr int TROW = AL<bf16_t, NT>::TROW;
+    float wf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wf[r] = w[r];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const bf16x8_t b = pack8(wf + 8 * g2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* rowp = m_lds + (32 * dt + l31) * TROW + (32 * t + 16 * g2 + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(rowp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(rowp + 16);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo, hi), b, o[dt], 0, 0, 0);
+      }
+    }
+  } else {
+    const float* ms = reinterpret_cast<const float*>(m_lds);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ms[key * 65 + 32 * dt + l31], w[r], o[dt], 0, 0, 0);
+    }
+  }
+}
+
+// ---- forward ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v, int64_t ld, T* out,
+                                                       int64_t ldo, int B, int H, int N, int Kp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = AL<T, NT>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const T* kb = k + (int64_t)b * N * ld + h * 64;
+  const T* vb = v + (int64_t)b * N * ld + h * 64;
+  char* ks = smem;
+  char* vs = smem + L::K_BYTES;
+  if constexpr (sizeof(T) == 2) {
+    stage_rows_bf16<NT, 512>(ks, kb, ld, N, tid);
+    stage_transposed_bf16<NT, 512>(vs, vb, ld, N, tid);
+  } else {
+    stage_rows_f32<NT, 512>(reinterpret_cast<float*>(ks), kb, ld, N, tid);
+    stage_rows_f32<NT, 512>(reinterpret_cast<float*>(vs), vb, ld, N, tid);
+  }
+  __syncthreads();
+
+  const int S = N + Kp;
+  for (int qt = wave; qt * 32 < S; qt += 8) {
+    // K/V fragments in LDS do not depend on the query tile; without this opaque copy the
+    // compiler hoists all of their ds_reads out of the loop and spills them to scratch
+    int l31v = l31;
+    asm volatile("" : "+v"(l31v));
+    const int s = qt * 32 + l31;
+    const int sc = min(s, S - 1);
+    const int64_t grow = sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
+    RowFrag<T> qf;
+    qf.load(q + grow * ld + h * 64, half);
+    f32x16_t acc[NT];
+    rows_times_frag<T, NT>(ks, qf, acc, l31v, half);
+    softmax_rows<T, NT>(acc, N, half, scale);
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) contract_keys<T, NT>(vs, t, acc[t], o, l31v, half);
+    if (s < S) {
+      T* orow = out + grow * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2],
+                        o[dt][4 * g + 3]);
+    }
+  }
+}
+
+// ---- backward (prompt rows only; dq) -----------------------------------------------------
+// dq = scale * (U - delta * W),  U = sum_key (p*dp)[key] K[key],  W = sum_key p[key] K[key],
+// delta = sum_key p*dp, dp = da . V^T.  One pass over the key tiles, no saved forward output.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
+                                                       const T* __restrict__ k, const T* __restrict__ v,
+                                                       int64_t ldkv, const T* __restrict__ da, int64_t ldda,
+                                                       T* dq, int64_t lddq, int B, int H, int N, int Kp,
+                                                       float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = AL<T, NT>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const T* kb = k + (int64_t)b * N * ldkv + h * 64;
+  const T* vb = v + (int64_t)b * N * ldkv + h * 64;
+  char* ks = smem;
+  char* vs = smem + L::K_BYTES;
+  char* kt = smem + 2 * L::K_BYTES;  // bf16 only
+  if constexpr (sizeof(T) == 2) {
+    stage_rows_bf16<NT, 256>(ks, kb, ldkv, N, tid);
+    stage_rows_bf16<NT, 256>(vs, vb, ldkv, N, tid);
+    stage_transposed_bf16<NT, 256>(kt, kb, ldkv, N, tid);
+  } else {
+    stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
+    stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
+    kt = ks;
+  }
+  __syncthreads();
+
+  for (int qt = wave; qt * 32 < Kp; qt += 4) {
+    int l31v = l31;
+    asm volatile("" : "+v"(l31v));
+    const int i = qt * 32 + l31;
+    const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
+    RowFrag<T> qf, df;
+    qf.load(qr + prow * ldq + h * 64, half);
+    df.load(da + prow * ldda + h * 64, half);
+    f32x16_t p[NT];
+    rows_times_frag<T, NT>(ks, qf, p, l31v, half);
+    softmax_rows<T, NT>(p, N, half, scale);
+    f32x16_t u[2], w[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { u[dt][r] = 0.f; w[dt][r] = 0.f; }
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16_t dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      if constexpr (sizeof(T) == 2) {
+        const char* rowp = vs + (32 * t + l31v) * 144 + half * 16;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + kk * 32);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df.f[kk], dp, 0, 0, 0);
+        }
+      } else {
+        const float* rowp = reinterpret_cast<const float*>(vs) + (32 * t + l31v) * 65 + half * 32;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk)
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[kk], df.f[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dp[r] *= p[t][r];           // p * dp  (p = 0 on padded keys)
+        delta += dp[r];
+      }
+      contract_keys<T, NT>(kt, t, dp, u, l31v, half);
+      contract_keys<T, NT>(kt, t, p[t], w, l31v, half);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (i < Kp) {
+      T* orow = dq + prow * lddq + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o4[j] = scale * (u[dt][4 * g + j] - delta * w[dt][4 * g + j]);
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o4[0], o4[1], o4[2], o4[3]);
+        }
+    }
+  }
+}
+
+template <typename T, int NT>
+int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
+               int N, int Kp, float scale, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = attn_fwd_kernel<T, NT>;
+  constexpr int bytes = AL<T, NT>::FWD_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),
+                     static_cast<const T*>(k), static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H,
+                     N, Kp, scale);
+  return rpo_launch_status();
+}
+
+template <typename T, int NT>
+int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* da,
+               int64_t ldda, void* dq, int64_t lddq, int B, int H, int N, int Kp, float scale, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = attn_bwd_kernel<T, NT>;
+  constexpr int bytes = AL<T, NT>::BWD_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
+                     static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
+                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale);
+  return rpo_launch_status();
+}
+
+bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
+
+}  // namespace
+
+extern "C" int rpo_attn_readonly_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out,
+                                     int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
+                                     void* stream) {
+  if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Kp < 0) return RPO_E_BADARG;
+  if (N > 288) return RPO_E_SHAPE;
+  if (dtype != RPO_F32 && dtype != RPO_BF16) return RPO_E_DTYPE;
+  const int esz = dtype == RPO_BF16 ? 2 : 4;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !ok_ld(ld, esz) ||
+      reinterpret_cast<uintptr_t>(out) % (4 * esz) || (ldo * esz) % (4 * esz)) return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16) {
+    if (N <= 224) return launch_fwd<bf16_t, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+    return launch_fwd<bf16_t, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+  }
+  if (N <= 224) return launch_fwd<float, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+  return launch_fwd<float, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+}
+
+extern "C" int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const void* v,
+                                     int64_t ldkv, const void* da, int64_t ldda, void* dq, int64_t lddq,
+                                     int dtype, int B, int H, int N, int Kp, float scale, void* stream) {
+  if (!q_rows || !k || !v || !da || !dq || B <= 0 || H <= 0 || N <= 0 || Kp <= 0) return RPO_E_BADARG;
+  if (N > 288 || Kp > 128) return RPO_E_SHAPE;
+  if (dtype != RPO_F32 && dtype != RPO_BF16) return RPO_E_DTYPE;
+  const int esz = dtype == RPO_BF16 ? 2 : 4;
+  if (!aligned16(q_rows) || !aligned16(k) || !aligned16(v) || !aligned16(da) || !ok_ld(ldq, esz) ||
+      !ok_ld(ldkv, esz) || !ok_ld(ldda, esz) || reinterpret_cast<uintptr_t>(dq) % (4 * esz) ||
+      (lddq * esz) % (4 * esz)) return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16) {
+    if (N <= 224) return launch_bwd<bf16_t, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+    return launch_bwd<bf16_t, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+  }
+  if (N <= 224) return launch_bwd<float, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+  return launch_bwd<float, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+}

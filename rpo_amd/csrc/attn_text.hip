@@ -1,0 +1,133 @@
+// Text-tower attention against per-class cached keys/values.
+//
+// Reference semantics: nn.MultiheadAttention with the per-class additive mask of
+// trainers/rpo.py:144-151 (causal AND column < len_c).  The K prompt rows sit at positions
+// len_c .. len_c+K-1 (:176-177), i.e. behind every allowed column, so each of them reads
+// exactly keys [0, len_c) of its class; frozen token t reads keys [0, min(t+1, len_c)).
+//
+// Sizes are tiny (<= 77 keys, head_dim 64 = one wave): this is a VALU kernel.  One workgroup
+// per (class, head) stages that class's K and V head slices in LDS once; each wave then
+// walks query rows.  head_dim 64 == wave size, so "lane = key" for the score / dP passes
+// and "lane = feature" for the P.V / dS.K passes; operands are broadcast with v_readlane.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float bcast(float v, int lane_uniform) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void text_attn_kernel(const T* __restrict__ q, int64_t ldq,
+                                                        const T* __restrict__ kc, const T* __restrict__ vc,
+                                                        int64_t ldkv, const T* __restrict__ da, int64_t ldda,
+                                                        T* out, int64_t ldo, const int32_t* __restrict__ len,
+                                                        int rows, int Lmax, int H, int causal, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Kf = reinterpret_cast<float*>(smem);
+  float* Vf = Kf + Lmax * 65;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x / H, h = blockIdx.x % H;
+  const int L = min(len[c], Lmax);
+  for (int id = tid; id < L * 64; id += 256) {
+    const int j = id >> 6, d = id & 63;
+    const int64_t off = ((int64_t)c * Lmax + j) * ldkv + h * 64 + d;
+    Kf[j * 65 + d] = ActIO<T>::ld(kc + off);
+    Vf[j * 65 + d] = ActIO<T>::ld(vc + off);
+  }
+  __syncthreads();
+  const int j0 = min(lane, Lmax - 1), j1 = min(lane + 64, Lmax - 1);
+  for (int r = wave; r < rows; r += 4) {
+    const int64_t row = (int64_t)c * rows + r;
+    const int nk = causal ? min(r + 1, L) : L;
+    const float qv = ActIO<T>::ld(q + row * ldq + h * 64 + lane);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) {
+      const float qd = bcast(qv, d);
+      s0 = fmaf(qd, Kf[j0 * 65 + d], s0);
+      s1 = fmaf(qd, Kf[j1 * 65 + d], s1);
+    }
+    s0 = lane < nk ? s0 * scale : -INFINITY;
+    s1 = lane + 64 < nk ? s1 * scale : -INFINITY;
+    const float m = wave_max(fmaxf(s0, s1));
+    float p0 = expf(s0 - m), p1 = expf(s1 - m);
+    const float inv = 1.0f / wave_sum(p0 + p1);
+    p0 *= inv; p1 *= inv;
+    if (!BWD) {
+      float acc = 0.f;
+      for (int j = 0; j < nk; ++j) {
+        const float pj = j < 64 ? bcast(p0, j) : bcast(p1, j - 64);
+        acc = fmaf(pj, Vf[j * 65 + lane], acc);
+      }
+      ActIO<T>::st(out + row * ldo + h * 64 + lane, acc);
+    } else {
+      const float dv = ActIO<T>::ld(da + row * ldda + h * 64 + lane);
+      float dp0 = 0.f, dp1 = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 64; ++d) {
+        const float dd = bcast(dv, d);
+        dp0 = fmaf(dd, Vf[j0 * 65 + d], dp0);
+        dp1 = fmaf(dd, Vf[j1 * 65 + d], dp1);
+      }
+      dp0 = lane < nk ? dp0 : 0.f;
+      dp1 = lane + 64 < nk ? dp1 : 0.f;
+      const float delta = wave_sum(p0 * dp0 + p1 * dp1);
+      const float ds0 = p0 * (dp0 - delta), ds1 = p1 * (dp1 - delta);
+      float acc = 0.f;
+      for (int j = 0; j < nk; ++j) {
+        const float dj = j < 64 ? bcast(ds0, j) : bcast(ds1, j - 64);
+        acc = fmaf(dj, Kf[j * 65 + lane], acc);
+      }
+      ActIO<T>::st(out + row * ldo + h * 64 + lane, acc * scale);
+    }
+  }
+}
+
+template <typename T, bool BWD>
+int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
+           int64_t ldda, void* out, int64_t ldo, const int32_t* len, int n_cls, int rows, int Lmax, int H,
+           int causal, float scale, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = text_attn_kernel<T, BWD>;
+  const int bytes = 2 * Lmax * 65 * 4;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 65 * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_cls * H), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
+                     static_cast<const T*>(kc), static_cast<const T*>(vc), ldkv, static_cast<const T*>(da), ldda,
+                     static_cast<T*>(out), ldo, len, rows, Lmax, H, causal, scale);
+  return rpo_launch_status();
+}
+
+}  // namespace
+
+extern "C" int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
+                                 void* out, int64_t ldo, int dtype, const int32_t* len, int n_cls, int rows,
+                                 int Lmax, int H, int causal, float scale, void* stream) {
+  if (!q || !kc || !vc || !out || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
+  if (Lmax > 128) return RPO_E_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16)
+    return launch<bf16_t, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
+  if (dtype == RPO_F32)
+    return launch<float, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
+  return RPO_E_DTYPE;
+}
+
+extern "C" int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
+                                 const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
+                                 const int32_t* len, int n_cls, int rows, int Lmax, int H, float scale,
+                                 void* stream) {
+  if (!q || !kc || !vc || !da || !dq || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
+  if (Lmax > 128) return RPO_E_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16)
+    return launch<bf16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);
+  if (dtype == RPO_F32)
+    return launch<float, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);
+  return RPO_E_DTYPE;
+}

@@ -1,0 +1,331 @@
+// Small HBM-bound kernels around the towers: patch im2col, token-matrix assembly, prompt
+// broadcast / gradient reduction, cosine-logit head + cross-entropy (fwd and bwd), SGD,
+// dtype conversion, and the MFMA layout probe used by the test-suite.
+#include "common.h"
+
+namespace {
+
+// ---- im2col for non-overlapping patches (trainers/rpo.py:198-200) -------------------------
+template <typename TO>
+__global__ void im2col_kernel(const float* __restrict__ img, TO* out, int64_t ldo, int B, int H, int W,
+                              int p, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (m, c, ky)
+  if (idx >= total) return;
+  const int g = W / p, gh = H / p;
+  const int ky = idx % p;
+  const int c = (idx / p) % 3;
+  const int m = idx / (3 * p);
+  const int px = m % g, py = (m / g) % gh, b = m / (g * gh);
+  const float* src = img + (((int64_t)b * 3 + c) * H + (py * p + ky)) * W + px * p;
+  TO* dst = out + (int64_t)m * ldo + (c * p + ky) * p;
+  for (int kx = 0; kx < p; ++kx) ActIO<TO>::st(dst + kx, src[kx]);
+  if (c == 2 && ky == p - 1)
+    for (int kx = 3 * p * p; kx < ldo; ++kx) ActIO<TO>::st(out + (int64_t)m * ldo + kx, 0.f);
+}
+
+__global__ void assemble_kernel(float* x, int64_t ldx, const float* __restrict__ cls,
+                                const float* __restrict__ pos0, const float* __restrict__ prompt, int B, int N,
+                                int Kp, int d) {
+  const int r = blockIdx.x;                 // 0..B-1: CLS rows; B.. : prompt rows
+  float* dst;
+  if (r < B) {
+    dst = x + (int64_t)r * N * ldx;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = cls[i] + pos0[i];
+  } else {
+    const int pr = r - B;                   // b*Kp + i
+    dst = x + ((int64_t)B * N + pr) * ldx;
+    const float* src = prompt + (int64_t)(pr % Kp) * d;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* dst, int64_t ld, int rows, int d) {
+  const int r = blockIdx.x;                 // g*rows + i
+  const float* s = src + (int64_t)(r % rows) * d;
+  float* o = dst + (int64_t)r * ld;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = s[i];
+}
+
+__global__ void reduce_groups_kernel(const float* __restrict__ src, int64_t ld, float* out, int groups, int rows,
+                                     int d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  const int i = idx / d, c = idx % d;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += src[((int64_t)g * rows + i) * ld + c];
+  out[idx] = s;
+}
+
+__global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, int64_t n, float lr, float mom,
+                           float wd, float gs, int first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float pi = p[i];
+  const float gi = gs * g[i] + wd * pi;
+  const float bi = first ? gi : mom * buf[i] + gi;
+  buf[i] = bi;
+  p[i] = pi - lr * bi;
+}
+
+template <typename TO>
+__global__ void convert_kernel(const float* __restrict__ src, int64_t lds, TO* dst, int64_t ldd, int rows,
+                               int cols) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  const int64_t r = idx / cols, c = idx % cols;
+  ActIO<TO>::st(dst + r * ldd + c, src[r * lds + c]);
+}
+
+// ---- head ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// unit vectors and inverse norms of every feature row (trainers/rpo.py:215-219)
+__global__ __launch_bounds__(256) void head_normalize_kernel(const float* __restrict__ f, float* unit,
+                                                             float* inv_norm, int rows, int e) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* x = f + (int64_t)r * e;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < e; i += 256) s += x[i] * x[i];
+  const float inv = 1.0f / sqrtf(block_sum(s, red));
+  for (int i = threadIdx.x; i < e; i += 256) unit[(int64_t)r * e + i] = x[i] * inv;
+  if (threadIdx.x == 0) inv_norm[r] = inv;
+}
+
+// logits[b,c] = (scale/K) * sum_{i,e} ih[b,i,e] th[c,i,e]   (trainers/rpo.py:221-227)
+__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ ih,
+                                                          const float* __restrict__ th, float* logits, int C,
+                                                          int Ke, float mul) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* x = ih + (int64_t)b * Ke;
+  const float* y = th + (int64_t)c * Ke;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < Ke; i += 256) s = fmaf(x[i], y[i], s);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) logits[(int64_t)b * C + c] = s * mul;
+}
+
+// per image: loss_b = logsumexp - logit[label]; dl[b,c] = (softmax - onehot) * gmul
+__global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ label, float* dl,
+                                                      float* loss_b, int C, float gmul) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* z = logits + (int64_t)b * C;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, z[c]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += expf(z[c] - m);
+  s = block_sum(s, red);
+  const int lb = (int)label[b];
+  const float inv = 1.0f / s;
+  for (int c = threadIdx.x; c < C; c += 256)
+    dl[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul;
+  if (threadIdx.x == 0) loss_b[b] = (m + logf(s)) - z[lb];
+}
+
+__global__ void head_loss_mean_kernel(const float* __restrict__ loss_b, float* loss, int B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += loss_b[b];
+    *loss = s / (float)B;
+  }
+}
+
+// one block per feature row (g, i) of the "self" side; other side has `n_other` groups.
+//   dh[e] = sum_o dl(g,o) * other_unit[o, i, e];  df = (dh - h * <h,dh>) * inv_norm
+// dl is indexed dl[g*sg + o*so] so the same kernel serves images (sg=C, so=1) and classes (sg=1, so=C).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, int64_t sg, int64_t so,
+                                                       const float* __restrict__ self_unit,
+                                                       const float* __restrict__ self_inv,
+                                                       const float* __restrict__ other_unit, float* df,
+                                                       int n_other, int K, int e) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;            // g*K + i
+  const int g = row / K, i = row % K;
+  const float* h = self_unit + (int64_t)row * e;
+  float dot = 0.f;
+  // e <= 4 * 256 handled in registers
+  float dh[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int o = 0; o < n_other; ++o) {
+    const float w = dl[g * sg + o * so];
+    const float* y = other_unit + ((int64_t)o * K + i) * e;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = threadIdx.x + 256 * v;
+      if (idx < e) dh[v] = fmaf(w, y[idx], dh[v]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = threadIdx.x + 256 * v;
+    if (idx < e) dot = fmaf(h[idx], dh[v], dot);
+  }
+  dot = block_sum(dot, red);
+  const float inv = self_inv[row];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = threadIdx.x + 256 * v;
+    if (idx < e) df[(int64_t)row * e + idx] = (dh[v] - h[idx] * dot) * inv;
+  }
+}
+
+// ---- MFMA layout probe ------------------------------------------------------------------------
+__global__ void probe_kernel(int which, const float* a, const float* b, float* d) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (which == 0) {
+    float fa[8], fb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fa[j] = a[l31 * 16 + half * 8 + j]; fb[j] = b[l31 * 16 + half * 8 + j]; }
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 ua, ub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ua[j] = pack_bf16x2(fa[2 * j], fa[2 * j + 1]); ub[j] = pack_bf16x2(fb[2 * j], fb[2 * j + 1]); }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ua), __builtin_bit_cast(bf16x8_t, ub), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[l31 * 2 + half], b[l31 * 2 + half], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // row: from operand A
+    d[i * 32 + l31] = acc[r];                           // col: from operand B
+  }
+}
+
+}  // namespace
+
+extern "C" int rpo_version(void) { return RPO_ABI_VERSION; }
+
+extern "C" const char* rpo_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case RPO_E_BADARG: return "rpo: null pointer or non-positive size";
+    case RPO_E_SHAPE: return "rpo: shape not supported by the kernel";
+    case RPO_E_DTYPE: return "rpo: dtype combination not supported";
+    case RPO_E_ALIGN: return "rpo: pointer or leading dimension not sufficiently aligned";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rpo: unknown error";
+  }
+}
+
+extern "C" int rpo_im2col_patches(const float* img, void* out, int out_dtype, int64_t ldo, int B, int H, int W,
+                                  int patch, void* stream) {
+  if (!img || !out || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return RPO_E_BADARG;
+  if (H % patch || W % patch || ldo < 3 * patch * patch) return RPO_E_SHAPE;
+  const int m = B * (H / patch) * (W / patch);
+  const int total = m * 3 * patch;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_dtype == RPO_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, img,
+                       static_cast<bf16_t*>(out), ldo, B, H, W, patch, total);
+  else if (out_dtype == RPO_F32)
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, img,
+                       static_cast<float*>(out), ldo, B, H, W, patch, total);
+  else return RPO_E_DTYPE;
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_img_assemble(float* x, int64_t ldx, const float* cls, const float* pos0,
+                                const float* img_prompt, int B, int N, int Kp, int d, void* stream) {
+  if (!x || !cls || !pos0 || B <= 0 || N <= 0 || Kp < 0 || d <= 0 || (Kp > 0 && !img_prompt)) return RPO_E_BADARG;
+  hipLaunchKernelGGL(assemble_kernel, dim3(B + B * Kp), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                     cls, pos0, img_prompt, B, N, Kp, d);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_broadcast_rows(const float* src, float* dst, int64_t ld, int groups, int rows, int d,
+                                  void* stream) {
+  if (!src || !dst || groups <= 0 || rows <= 0 || d <= 0) return RPO_E_BADARG;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(groups * rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, dst, ld, rows, d);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_reduce_groups(const float* src, int64_t ld, float* out, int groups, int rows, int d,
+                                 void* stream) {
+  if (!src || !out || groups <= 0 || rows <= 0 || d <= 0) return RPO_E_BADARG;
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3((rows * d + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, ld, out, groups, rows, d);
+  return rpo_launch_status();
+}
+
+extern "C" int64_t rpo_head_workspace_floats(int B, int C, int K, int e) {
+  return (int64_t)(B + C) * K * e + (int64_t)(B + C) * K + (int64_t)B * C + B;
+}
+
+extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
+                                float* logits, float* loss, float* d_img_f, float* d_text_f, int B, int C, int K,
+                                int e, float* ws, void* stream) {
+  if (!img_f || !text_f || !logits || !ws || B <= 0 || C <= 0 || K <= 0 || e <= 0) return RPO_E_BADARG;
+  if (label && (!loss || !d_img_f || !d_text_f)) return RPO_E_BADARG;
+  if (e > 1024) return RPO_E_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* ih = ws;
+  float* th = ih + (int64_t)B * K * e;
+  float* ni = th + (int64_t)C * K * e;
+  float* nt = ni + (int64_t)B * K;
+  float* dl = nt + (int64_t)C * K;
+  float* lb = dl + (int64_t)B * C;
+  hipLaunchKernelGGL(head_normalize_kernel, dim3(B * K), dim3(256), 0, s, img_f, ih, ni, B * K, e);
+  hipLaunchKernelGGL(head_normalize_kernel, dim3(C * K), dim3(256), 0, s, text_f, th, nt, C * K, e);
+  hipLaunchKernelGGL(head_logits_kernel, dim3(C, B), dim3(256), 0, s, ih, th, logits, C, K * e,
+                     scale_exp / (float)K);
+  if (label) {
+    const float gmul = scale_exp / ((float)K * (float)B);
+    hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
+    hipLaunchKernelGGL(head_loss_mean_kernel, dim3(1), dim3(64), 0, s, lb, loss, B);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K), dim3(256), 0, s, dl, (int64_t)C, (int64_t)1, ih, ni, th,
+                       d_img_f, C, K, e);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(C * K), dim3(256), 0, s, dl, (int64_t)1, (int64_t)C, th, nt, ih,
+                       d_text_f, B, K, e);
+  }
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                            float grad_scale, int first_step, void* stream) {
+  if (!p || !g || !buf || n <= 0) return RPO_E_BADARG;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int rows,
+                           int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return RPO_E_BADARG;
+  const int64_t n = (int64_t)rows * cols;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dst_dtype == RPO_BF16)
+    hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
+                       static_cast<bf16_t*>(dst), ldd, rows, cols);
+  else if (dst_dtype == RPO_F32)
+    hipLaunchKernelGGL(convert_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
+                       static_cast<float*>(dst), ldd, rows, cols);
+  else return RPO_E_DTYPE;
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_probe_mfma(int which, const float* a, const float* b, float* d, void* stream) {
+  if (!a || !b || !d || (which != 0 && which != 1)) return RPO_E_BADARG;
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), which, a, b, d);
+  return rpo_launch_status();
+}

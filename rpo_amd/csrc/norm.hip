@@ -1,0 +1,185 @@
+// LayerNorm forward / backward-to-input, one wave per row (HBM-bound: each row is read
+// once with 16-B loads, reduced with wave shuffles, written once).
+//
+// Replaces the reference's fp32-upcast LayerNorm (clip/model.py:153-159: ln_1, ln_2,
+// ln_pre, ln_post, ln_final) and autograd through it.  Statistics are two-pass in
+// registers (mean, then centred second moment), biased variance, eps inside the rsqrt --
+// the same formula torch's CPU kernel evaluates.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 8;   // float4 per lane: d <= 64 * 4 * 8 = 2048
+
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TY* y, int64_t ldy,
+                                                     int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv4 = d >> 2;
+  const float* xr = x + (int64_t)row * ldx;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+      q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  TY* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
+      ActIO<TY>::st4(yr + 4 * c, (v[i].x - mu) * rstd * g.x + b.x, (v[i].y - mu) * rstd * g.y + b.y,
+                     (v[i].z - mu) * rstd * g.z + b.z, (v[i].w - mu) * rstd * g.w + b.w);
+    }
+  }
+}
+
+template <typename T> __device__ __forceinline__ float4 load4f(const T* p);
+template <> __device__ __forceinline__ float4 load4f<float>(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+template <typename TDY, typename TC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
+                                                     const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ dres, int64_t lddres,
+                                                     float* dx, int64_t lddx, TC* dxc, int64_t ldc,
+                                                     int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv4 = d >> 2;
+  const float* xr = x + (int64_t)row * ldx;
+  const TDY* dyr = dy + (int64_t)row * lddy;
+  float4 v[MAXV], g[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      const float4 w = *reinterpret_cast<const float4*>(gamma + 4 * c);
+      const float4 t = load4f<TDY>(dyr + 4 * c);
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
+      g[i] = make_float4(t.x * w.x, t.y * w.y, t.z * w.z, t.w * w.w);
+      sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      sgx += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+  }
+  const float mg = wave_sum(sg) / (float)d;
+  const float mgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) {
+      float4 o = make_float4(rstd * (g[i].x - mg - v[i].x * mgx), rstd * (g[i].y - mg - v[i].y * mgx),
+                             rstd * (g[i].z - mg - v[i].z * mgx), rstd * (g[i].w - mg - v[i].w * mgx));
+      if (dres != nullptr) {
+        const float4 r = *reinterpret_cast<const float4*>(dres + (int64_t)row * lddres + 4 * c);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
+      if (dxc != nullptr) ActIO<TC>::st4(dxc + (int64_t)row * ldc + 4 * c, o.x, o.y, o.z, o.w);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                 void* y, int64_t ldy, int y_dtype, int rows, int d, float eps,
+                                 void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || d <= 0) return RPO_E_BADARG;
+  if (d % 4 != 0 || d > 64 * 4 * MAXV) return RPO_E_SHAPE;
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || ldx % 4 != 0 || ldy % 4 != 0) return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (y_dtype == RPO_F32) {
+    if (!aligned16(y)) return RPO_E_ALIGN;
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, x, ldx, gamma, beta,
+                       static_cast<float*>(y), ldy, rows, d, eps);
+  } else if (y_dtype == RPO_BF16) {
+    if (reinterpret_cast<uintptr_t>(y) % 8) return RPO_E_ALIGN;
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, x, ldx, gamma, beta,
+                       static_cast<bf16_t*>(y), ldy, rows, d, eps);
+  } else {
+    return RPO_E_DTYPE;
+  }
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
+                                 const float* gamma, const float* dres, int64_t lddres, float* dx,
+                                 int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast, int rows,
+                                 int d, float eps, void* stream) {
+  if (!dy || !x || !gamma || !dx || rows <= 0 || d <= 0) return RPO_E_BADARG;
+  if (d % 4 != 0 || d > 64 * 4 * MAXV) return RPO_E_SHAPE;
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(dx) || ldx % 4 || lddx % 4 || lddy % 4) return RPO_E_ALIGN;
+  if (dres && (!aligned16(dres) || lddres % 4)) return RPO_E_ALIGN;
+  if (dx_cast && (reinterpret_cast<uintptr_t>(dx_cast) % 8 || ldcast % 4)) return RPO_E_ALIGN;
+  if (reinterpret_cast<uintptr_t>(dy) % (dy_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((rows + 3) / 4), block(256);
+#define RPO_LN_BWD(TDY, TC)                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), grid, block, 0, s, static_cast<const TDY*>(dy), lddy, \
+                     x, ldx, gamma, dres, lddres, dx, lddx, static_cast<TC*>(dx_cast), ldcast, rows, \
+                     d, eps)
+  const bool cast_bf16 = dx_cast != nullptr && cast_dtype == RPO_BF16;
+  if (dx_cast != nullptr && cast_dtype != RPO_BF16 && cast_dtype != RPO_F32) return RPO_E_DTYPE;
+  if (dy_dtype == RPO_F32) {
+    if (cast_bf16) RPO_LN_BWD(float, bf16_t); else RPO_LN_BWD(float, float);
+  } else if (dy_dtype == RPO_BF16) {
+    if (cast_bf16) RPO_LN_BWD(bf16_t, bf16_t); else RPO_LN_BWD(bf16_t, float);
+  } else {
+    return RPO_E_DTYPE;
+  }
+#undef RPO_LN_BWD
+  return rpo_launch_status();
+}

@@ -1,0 +1,73 @@
+"""Data-parallel plumbing: one process per GPU, RCCL over xGMI (backend "nccl" on ROCm).
+
+The reference's multi-GPU mode is ``nn.DataParallel`` (trainers/rpo.py:280-285),
+which re-broadcasts the 150 M frozen parameters every step and cannot even
+back-propagate RPO's per-replica scalar loss (SURVEY.md finding 8).  Here every
+rank keeps the frozen backbone resident and never communicates it; images are
+independent units, so the global batch is sharded evenly and the ONLY collective
+per step is a sum all-reduce of the flat prompt-gradient buffer
+([K*d_t + K*d_v] fp32 = 122 880 B at K=24).  Each rank's loss is the mean over
+its shard; with equal shards the mean of shard means is the global mean, so
+summing gradients and scaling by 1/world_size (folded into rpo_sgd_step's
+grad_scale) reproduces single-process training on the global batch.
+
+On CPU tensors the same code runs over gloo -- that is how tests/ cover it.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, backend: Optional[str] = None, init: bool = True):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.enabled = self.world_size > 1
+        if self.enabled and init and not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world_size
+
+    def shard(self, global_batch: int) -> Tuple[int, int]:
+        """(first image, count) of this rank's contiguous shard; shards must be equal so that
+        the mean of shard means is the global mean."""
+        if global_batch % self.world_size != 0:
+            raise ValueError(f"global batch {global_batch} not divisible by world size {self.world_size}")
+        per = global_batch // self.world_size
+        return self.rank * per, per
+
+    def all_reduce_sum(self, flat: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.enabled:
+            dist.broadcast(t, src=src)
+        return t
+
+    def max_over_ranks(self, value: float, device) -> float:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self) -> None:
+        if self.enabled:
+            dist.barrier()
+
+    def close(self) -> None:
+        if self.enabled and dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,0 +1,361 @@
+"""Kernel sequencing for one RPO step on one MI355X.
+
+This is the host-side counterpart of what sits under ``CustomCLIP.forward``
+in the reference (trainers/rpo.py:161-232 calling clip/model.py:188-207): it
+owns the packed frozen weights and the activation workspace in HBM and
+enqueues librpo_hip.so kernels on HIP streams.  It exploits the read-only
+structure (SURVEY.md finding 4): nothing reads a prompt, so
+
+* the image tower's frozen tokens run inference-only and all S = N + K rows of
+  every image share each layer's GEMM launches,
+* the text tower's frozen tokens are run ONCE (``cache_text_kv``), leaving the
+  n_cls*K prompt rows per step,
+* the backward touches only the B*K / n_cls*K prompt rows (contiguous at the
+  bottom of the row layout) and needs only dX GEMMs (weights are frozen).
+
+Row layout of the image tower: [B*N frozen rows | B*K prompt rows], see
+include/rpo_amd.h.  All HBM buffers are allocated once, sized for ``max_batch``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH, EPI_QGELU_BWD
+from .config import RPOConfig
+
+SCALE = 1.0 / math.sqrt(64.0)
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class _Block:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    w_in: torch.Tensor; b_in: torch.Tensor          # [3d, d], [3d]
+    w_out: torch.Tensor; b_out: torch.Tensor        # [d, d]
+    w_fc: torch.Tensor; b_fc: torch.Tensor          # [4d, d]
+    w_proj: torch.Tensor; b_proj: torch.Tensor      # [d, 4d]
+    w_q_t: torch.Tensor                             # [d, d]   = w_in[:d].T      (dX of the q projection)
+    w_out_t: torch.Tensor                           # [d, d]
+    w_fc_t: torch.Tensor                            # [d, 4d]
+    w_proj_t: torch.Tensor                          # [4d, d]
+
+
+class Engine:
+    def __init__(self, cfg: RPOConfig, state_dict: Dict[str, np.ndarray], tokens: np.ndarray,
+                 device: torch.device, act_dtype: torch.dtype = torch.bfloat16, max_batch: int = 32):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rpo_amd.Engine needs a HIP device; there is no CPU path")
+        ops.version()                                   # loads the library or raises
+        self.cfg, self.dev, self.act = cfg, device, act_dtype
+        self.max_batch = max_batch
+        self.kmult = 64 if act_dtype == torch.bfloat16 else 32
+        tokens = np.asarray(tokens, dtype=np.int64)
+        assert tokens.shape == (cfg.n_cls, cfg.context)
+        self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
+        assert int(self.len_np.max()) + cfg.K <= cfg.context, "len_c + K must fit the context (rpo.py:176)"
+        self.Lmax = int(self.len_np.max())
+        self.len_i32 = torch.tensor(self.len_np, dtype=torch.int32, device=device)
+        self.logit_scale_exp = float(np.exp(np.float32(state_dict["logit_scale"])))
+        self._pack(state_dict, tokens)
+        self._alloc()
+        self.text_cache_ready = False
+
+    # ------------------------------------------------------------------ weights
+    def _f32(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
+
+    def _act(self, w: torch.Tensor) -> torch.Tensor:
+        """fp32 device matrix -> act dtype via the library's convert kernel."""
+        w = w.contiguous()
+        if self.act == torch.float32:
+            return w
+        out = torch.empty(w.shape, dtype=self.act, device=self.dev)
+        return ops.convert(w, out)
+
+    def _block(self, sd, p: str) -> _Block:
+        g = lambda k: self._f32(sd[p + k])
+        w_in, w_out, w_fc, w_proj = g("attn.in_proj_weight"), g("attn.out_proj.weight"), g("mlp.c_fc.weight"), g("mlp.c_proj.weight")
+        d = w_out.shape[0]
+        return _Block(
+            ln1_w=g("ln_1.weight"), ln1_b=g("ln_1.bias"), ln2_w=g("ln_2.weight"), ln2_b=g("ln_2.bias"),
+            w_in=self._act(w_in), b_in=g("attn.in_proj_bias"), w_out=self._act(w_out), b_out=g("attn.out_proj.bias"),
+            w_fc=self._act(w_fc), b_fc=g("mlp.c_fc.bias"), w_proj=self._act(w_proj), b_proj=g("mlp.c_proj.bias"),
+            w_q_t=self._act(w_in[:d].t()), w_out_t=self._act(w_out.t()), w_fc_t=self._act(w_fc.t()),
+            w_proj_t=self._act(w_proj.t()))
+
+    def _pack(self, sd, tokens) -> None:
+        cfg = self.cfg
+        self.vis = [self._block(sd, f"visual.transformer.resblocks.{l}.") for l in range(cfg.layers_v)]
+        self.txt = [self._block(sd, f"transformer.resblocks.{l}.") for l in range(cfg.layers_t)]
+        self.kpatch = _round_up(cfg.patch_dim, self.kmult)
+        conv = torch.zeros(cfg.d_v, self.kpatch, device=self.dev)
+        conv[:, :cfg.patch_dim] = self._f32(sd["visual.conv1.weight"]).reshape(cfg.d_v, -1)
+        self.conv_w = self._act(conv)
+        self.cls = self._f32(sd["visual.class_embedding"])
+        self.pos = self._f32(sd["visual.positional_embedding"])
+        self.ln_pre = (self._f32(sd["visual.ln_pre.weight"]), self._f32(sd["visual.ln_pre.bias"]))
+        self.ln_post = (self._f32(sd["visual.ln_post.weight"]), self._f32(sd["visual.ln_post.bias"]))
+        self.ln_final = (self._f32(sd["ln_final.weight"]), self._f32(sd["ln_final.bias"]))
+        vp, tp = self._f32(sd["visual.proj"]), self._f32(sd["text_projection"])      # [d, e]
+        self.img_proj_t, self.img_proj = self._act(vp.t()), self._act(vp)           # fwd W=[e,d]; bwd W=[d,e]
+        self.text_proj_t, self.text_proj = self._act(tp.t()), self._act(tp)
+        # make_prompts (trainers/rpo.py:135-136): tok_emb[ids] + pos, kept for the frozen tokens only
+        tx = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][None]
+        self.text_x_frozen = self._f32(tx[:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
+
+    # ------------------------------------------------------------------ workspace
+    def _alloc(self) -> None:
+        cfg, dev, act = self.cfg, self.dev, self.act
+        B, N, K, dv, dt, e = self.max_batch, cfg.n_frozen, cfg.K, cfg.d_v, cfg.d_t, cfg.embed
+        R, Rp = B * (N + K), B * K
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        a = lambda *s: torch.empty(*s, dtype=act, device=dev)
+        Lv, Lt = cfg.layers_v, cfg.layers_t
+        self.im2col = a(B * cfg.n_patches, self.kpatch)
+        self.x_pre = f32(R, dv)
+        self.x = [f32(R, dv) for _ in range(Lv + 1)]
+        self.xm = [f32(R, dv) for _ in range(Lv)]
+        self.h = a(R, dv)
+        self.qkv = [a(R, 3 * dv) for _ in range(Lv)]
+        self.att = a(R, dv)
+        self.g = a(R, 4 * dv)
+        self.u = [f32(Rp, 4 * dv) for _ in range(Lv)]
+        self.y_post = a(Rp, dv)
+        self.img_f = f32(Rp, e)
+        # backward temporaries (prompt rows)
+        self.d_img_f = f32(Rp, e)
+        self.d_img_f_a = a(Rp, e)
+        self.dy_v = f32(Rp, dv)
+        self.dxa_v, self.dxb_v = f32(Rp, dv), f32(Rp, dv)
+        self.dxc_v = a(Rp, dv)
+        self.du_v = a(Rp, 4 * dv)
+        self.da_v, self.dq_v = a(Rp, dv), a(Rp, dv)
+        # text tower (prompt rows per step)
+        Rt = cfg.n_cls * K
+        self.Rt = Rt
+        self.xt = [f32(Rt, dt) for _ in range(Lt + 1)]
+        self.xtm = [f32(Rt, dt) for _ in range(Lt)]
+        self.ht = a(Rt, dt)
+        self.qt = [a(Rt, dt) for _ in range(Lt)]
+        self.att_t = a(Rt, dt)
+        self.gt = a(Rt, 4 * dt)
+        self.ut = [f32(Rt, 4 * dt) for _ in range(Lt)]
+        self.y_final = a(Rt, dt)
+        self.text_f = f32(Rt, e)
+        self.d_text_f = f32(Rt, e)
+        self.d_text_f_a = a(Rt, e)
+        self.dy_t = f32(Rt, dt)
+        self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
+        self.dxc_t = a(Rt, dt)
+        self.du_t = a(Rt, 4 * dt)
+        self.da_t, self.dq_t = a(Rt, dt), a(Rt, dt)
+        # frozen text K/V cache: per layer [n_cls*Lmax, 2*dt] (k | v)
+        self.kv_t = [a(cfg.n_cls * self.Lmax, 2 * dt) for _ in range(Lt)]
+        # head
+        self.logits = f32(B, cfg.n_cls)
+        self.loss = f32(1)
+        self.head_ws = f32(ops.head_workspace_floats(B, cfg.n_cls, K, e))
+        # parameters / gradients / momentum: one flat buffer each [text | img]
+        nt, ni = K * dt, K * dv
+        self.params = f32(nt + ni)
+        self.grads = torch.zeros(nt + ni, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(nt + ni, dtype=torch.float32, device=dev)
+        self.text_prompt = self.params[:nt].view(K, dt)
+        self.img_prompt = self.params[nt:].view(K, dv)
+        self.g_text = self.grads[:nt].view(K, dt)
+        self.g_img = self.grads[nt:].view(K, dv)
+        self.side = torch.cuda.Stream(device=dev)
+
+    def hbm_bytes(self) -> int:
+        tot = 0
+        for v in vars(self).values():
+            ts = v if isinstance(v, (list, tuple)) else [v]
+            for t in ts:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    tot += t.numel() * t.element_size()
+        return tot
+
+    # ------------------------------------------------------------------ one-off text pass
+    def cache_text_kv(self) -> None:
+        """Frozen text tokens (positions < len_c) of every class through all blocks with the
+        causal AND col<len_c mask (trainers/rpo.py:146-149); keeps each layer's K and V.
+        Independent of prompts and images, so it runs once per class set."""
+        cfg, act = self.cfg, self.act
+        n, L, dt, H = cfg.n_cls, self.Lmax, cfg.d_t, cfg.heads_t
+        Rf = n * L
+        x = self.text_x_frozen.clone()
+        xm = torch.empty_like(x)
+        h = torch.empty(Rf, dt, dtype=act, device=self.dev)
+        qkv = torch.empty(Rf, 3 * dt, dtype=act, device=self.dev)
+        att = torch.empty(Rf, dt, dtype=act, device=self.dev)
+        g = torch.empty(Rf, 4 * dt, dtype=act, device=self.dev)
+        for l, blk in enumerate(self.txt):
+            ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
+            ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in)
+            ops.text_attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], att, self.len_i32, n, L, L, H,
+                              causal=True, scale=SCALE)
+            self.kv_t[l].copy_(qkv[:, dt:])
+            ops.gemm_nt(att, blk.w_out, xm, EPI_BIAS_RESID, bias=blk.b_out, resid=x)
+            ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, h)
+            ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc, aux=None, aux_row0=Rf)
+            ops.gemm_nt(g, blk.w_proj, x, EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
+        self.text_cache_ready = True
+
+    # ------------------------------------------------------------------ forward pieces
+    def _text_forward(self, train: bool) -> None:
+        cfg = self.cfg
+        n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
+        ops.broadcast_rows(self.text_prompt, self.xt[0], n)          # trainers/rpo.py:176-177
+        for l, blk in enumerate(self.txt):
+            kv = self.kv_t[l]
+            ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
+            ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt])
+            ops.text_attn_fwd(self.qt[l], kv[:, :dt], kv[:, dt:], self.att_t, self.len_i32, n, K, self.Lmax, H,
+                              causal=False, scale=SCALE)
+            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l])
+            ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
+            ops.gemm_nt(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
+                        aux=self.ut[l] if train else None, aux_row0=0)
+            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l])
+        ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
+        ops.gemm_nt(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
+
+    def _image_forward(self, image: torch.Tensor, train: bool) -> None:
+        cfg = self.cfg
+        B, N, K, dv, H = image.shape[0], cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
+        Rf, Rp = B * N, B * K
+        R = Rf + Rp
+        x_pre = self.x_pre[:R]
+        ops.im2col_patches(image, self.im2col[:B * cfg.n_patches], cfg.patch)
+        ops.gemm_nt(self.im2col[:B * cfg.n_patches], self.conv_w, x_pre, EPI_PATCH, resid=self.pos,
+                    group=cfg.n_patches)                                               # rpo.py:198-202
+        ops.img_assemble(x_pre, self.cls, self.pos, self.img_prompt, B, N, K)          # rpo.py:201-204
+        ops.layernorm_fwd(x_pre, self.ln_pre[0], self.ln_pre[1], self.x[0][:R])        # rpo.py:206
+        h, att, g = self.h[:R], self.att[:R], self.g[:R]
+        for l, blk in enumerate(self.vis):
+            x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
+            ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
+            # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
+            ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
+            ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
+            ops.gemm_nt(att, blk.w_out, xm, EPI_BIAS_RESID, bias=blk.b_out, resid=x)
+            ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, h)
+            ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc,
+                        aux=self.u[l][:Rp] if train else None, aux_row0=Rf)
+            ops.gemm_nt(g, blk.w_proj, xo, EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
+        ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
+        ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
+
+    # ------------------------------------------------------------------ backward pieces
+    def _rows_backward(self, blocks: List[_Block], x: List[torch.Tensor], xm: List[torch.Tensor],
+                       u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd) -> torch.Tensor:
+        """Shared by both towers: dx (fp32, in dxa) holds dL/d(block output) on entry; on return the
+        tensor holding dL/d(block-0 input).  dxc mirrors dx in the act dtype (GEMM A operand)."""
+        for l in reversed(range(len(blocks))):
+            blk = blocks[l]
+            a_in = dxa if self.act == torch.float32 else dxc
+            ops.gemm_nt(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l])          # d c_proj, d QuickGELU
+            ops.gemm_nt(du, blk.w_fc_t, dy, EPI_NONE)                             # d c_fc
+            ops.layernorm_bwd(dy, xm[l], blk.ln2_w, dxa, dxb, None if self.act == torch.float32 else dxc)
+            a_in = dxb if self.act == torch.float32 else dxc
+            ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                          # d out_proj
+            attn_bwd(l, da, dq)
+            ops.gemm_nt(dq, blk.w_q_t, dy, EPI_NONE)                              # d q-projection
+            ops.layernorm_bwd(dy, x[l], blk.ln1_w, dxb, dxa, None if self.act == torch.float32 else dxc)
+        return dxa
+
+    def _image_backward(self, B: int) -> None:
+        cfg = self.cfg
+        N, K, dv, H = cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
+        Rf, Rp = B * N, B * K
+        R = Rf + Rp
+        dxa, dxb, dxc = self.dxa_v[:Rp], self.dxb_v[:Rp], self.dxc_v[:Rp]
+        if self.act == torch.float32:
+            d_f = self.d_img_f[:Rp]
+        else:
+            d_f = ops.convert(self.d_img_f[:Rp], self.d_img_f_a[:Rp])
+        ops.gemm_nt(d_f, self.img_proj, self.dy_v[:Rp], EPI_NONE)
+        ops.layernorm_bwd(self.dy_v[:Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
+                          None if self.act == torch.float32 else dxc)
+
+        def attn_bwd(l, da, dq):
+            qkv = self.qkv[l]
+            ops.attn_readonly_bwd(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da, dq, B, H, N, K, SCALE)
+
+        dx = self._rows_backward(self.vis, [t[Rf:R] for t in self.x[:-1]], [t[Rf:R] for t in self.xm],
+                                 [t[:Rp] for t in self.u], dxa, dxb, dxc, self.du_v[:Rp], self.da_v[:Rp],
+                                 self.dq_v[:Rp], self.dy_v[:Rp], attn_bwd)
+        # through ln_pre (rpo.py:206) to the appended prompt rows, then sum over the batch (.repeat, :204)
+        ops.layernorm_bwd(dx, self.x_pre[Rf:R], self.ln_pre[0], None, dxb)
+        ops.reduce_groups(dxb, self.g_img, B)
+
+    def _text_backward(self) -> None:
+        cfg = self.cfg
+        n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
+        dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
+        d_f = self.d_text_f if self.act == torch.float32 else ops.convert(self.d_text_f, self.d_text_f_a)
+        ops.gemm_nt(d_f, self.text_proj, self.dy_t, EPI_NONE)
+        ops.layernorm_bwd(self.dy_t, self.xt[-1], self.ln_final[0], None, dxa,
+                          None if self.act == torch.float32 else dxc)
+
+        def attn_bwd(l, da, dq):
+            kv = self.kv_t[l]
+            ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
+
+        dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
+                                 self.dq_t, self.dy_t, attn_bwd)
+        ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
+
+    # ------------------------------------------------------------------ public
+    def forward_eval(self, image: torch.Tensor) -> torch.Tensor:
+        """logits[B, n_cls] (trainers/rpo.py:232)."""
+        B = self._check(image)
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._text_forward(train=False)
+        self._image_forward(image, train=False)
+        main.wait_stream(self.side)
+        K, e = self.cfg.K, self.cfg.embed
+        ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(self.cfg.n_cls, K, e), None,
+                         self.logit_scale_exp, self.logits[:B], None, None, None, self.head_ws)
+        return self.logits[:B]
+
+    def forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
+        """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in
+        self.loss, self.logits, self.grads (= [g_text | g_img]).  Capturable in a HIP graph."""
+        B = self._check(image)
+        assert label.dtype == torch.int64 and label.shape == (B,)
+        K, e, n = self.cfg.K, self.cfg.embed, self.cfg.n_cls
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._text_forward(train=True)
+        self._image_forward(image, train=True)
+        main.wait_stream(self.side)
+        ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(n, K, e), label, self.logit_scale_exp,
+                         self.logits[:B], self.loss, self.d_img_f[:B * K].view(B, K, e),
+                         self.d_text_f.view(n, K, e), self.head_ws)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._text_backward()
+        self._image_backward(B)
+        main.wait_stream(self.side)
+
+    def _check(self, image: torch.Tensor) -> int:
+        cfg = self.cfg
+        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous()
+        B = image.shape[0]
+        assert 1 <= B <= self.max_batch and tuple(image.shape[1:]) == (3, cfg.image_size, cfg.image_size)
+        if not self.text_cache_ready:
+            self.cache_text_kv()
+        return B

@@ -1,0 +1,183 @@
+"""Thin torch-tensor front-end of the C ABI (include/rpo_amd.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every function
+below only passes ``data_ptr()``s, sizes and the current HIP stream to
+librpo_hip.so.  No computation happens in torch, and there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH, EPI_QGELU_BWD, RPO_BF16,
+                   RPO_F32, GemmArgs, check)
+
+LN_EPS = 1e-5
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return RPO_F32
+    if t == torch.bfloat16:
+        return RPO_BF16
+    raise TypeError(f"unsupported dtype {t}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view required"
+    return t.stride(0)
+
+
+def version() -> int:
+    return _lib.load().rpo_version()
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
+            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+            aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
+            group: int = 0, m_rows: Optional[int] = None) -> torch.Tensor:
+    """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
+    (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``."""
+    M = a.shape[0] if m_rows is None else m_rows
+    N, K = w.shape
+    assert a.shape[1] == K and a.dtype == w.dtype
+    args = GemmArgs(A=a.data_ptr(), lda=_ld(a), W=w.data_ptr(), ldw=_ld(w), C=out.data_ptr(), ldc=_ld(out),
+                    M=M, N=N, K=K, in_dtype=dtype_code(a.dtype), out_dtype=dtype_code(out.dtype),
+                    epilogue=epilogue, bias=_p(bias), resid=_p(resid), ldr=0 if resid is None else _ld(resid),
+                    aux=_p(aux), ldaux=0 if aux is None else _ld(aux), aux_row0=aux_row0,
+                    skip_row0=skip_row0, skip_col0=skip_col0, group=group)
+    check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,
+                  eps: float = LN_EPS) -> torch.Tensor:
+    assert x.dtype == torch.float32
+    check(_lib.load().rpo_layernorm_fwd(x.data_ptr(), _ld(x), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                        _ld(y), dtype_code(y.dtype), x.shape[0], x.shape[1], eps, _stream()),
+          "rpo_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres: Optional[torch.Tensor],
+                  dx: torch.Tensor, dx_cast: Optional[torch.Tensor] = None, eps: float = LN_EPS) -> torch.Tensor:
+    assert x.dtype == torch.float32 and dx.dtype == torch.float32
+    check(_lib.load().rpo_layernorm_bwd(
+        dy.data_ptr(), dtype_code(dy.dtype), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(),
+        _p(dres), 0 if dres is None else _ld(dres), dx.data_ptr(), _ld(dx), _p(dx_cast),
+        RPO_F32 if dx_cast is None else dtype_code(dx_cast.dtype), 0 if dx_cast is None else _ld(dx_cast),
+        x.shape[0], x.shape[1], eps, _stream()), "rpo_layernorm_bwd")
+    return dx
+
+
+def im2col_patches(img: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Tensor:
+    B, Cc, H, W = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    check(_lib.load().rpo_im2col_patches(img.data_ptr(), out.data_ptr(), dtype_code(out.dtype), _ld(out), B, H, W,
+                                         patch, _stream()), "rpo_im2col_patches")
+    return out
+
+
+def img_assemble(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, img_prompt: torch.Tensor, B: int, N: int,
+                 Kp: int) -> torch.Tensor:
+    check(_lib.load().rpo_img_assemble(x.data_ptr(), _ld(x), cls.data_ptr(), pos.data_ptr(), img_prompt.data_ptr(),
+                                       B, N, Kp, x.shape[1], _stream()), "rpo_img_assemble")
+    return x
+
+
+def broadcast_rows(src: torch.Tensor, dst: torch.Tensor, groups: int) -> torch.Tensor:
+    rows, d = src.shape
+    assert src.is_contiguous() and dst.shape[0] >= groups * rows
+    check(_lib.load().rpo_broadcast_rows(src.data_ptr(), dst.data_ptr(), _ld(dst), groups, rows, d, _stream()),
+          "rpo_broadcast_rows")
+    return dst
+
+
+def reduce_groups(src: torch.Tensor, out: torch.Tensor, groups: int) -> torch.Tensor:
+    rows, d = out.shape
+    assert out.is_contiguous()
+    check(_lib.load().rpo_reduce_groups(src.data_ptr(), _ld(src), out.data_ptr(), groups, rows, d, _stream()),
+          "rpo_reduce_groups")
+    return out
+
+
+def attn_readonly_fwd(q, k, v, out, B: int, H: int, N: int, Kp: int, scale: float = 0.125):
+    assert _ld(q) == _ld(k) == _ld(v)
+    check(_lib.load().rpo_attn_readonly_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(q), out.data_ptr(),
+                                            _ld(out), dtype_code(q.dtype), B, H, N, Kp, scale, _stream()),
+          "rpo_attn_readonly_fwd")
+    return out
+
+
+def attn_readonly_bwd(q_rows, k, v, da, dq, B: int, H: int, N: int, Kp: int, scale: float = 0.125):
+    assert _ld(k) == _ld(v)
+    check(_lib.load().rpo_attn_readonly_bwd(q_rows.data_ptr(), _ld(q_rows), k.data_ptr(), v.data_ptr(), _ld(k),
+                                            da.data_ptr(), _ld(da), dq.data_ptr(), _ld(dq),
+                                            dtype_code(q_rows.dtype), B, H, N, Kp, scale, _stream()),
+          "rpo_attn_readonly_bwd")
+    return dq
+
+
+def text_attn_fwd(q, kc, vc, out, len_i32, n_cls: int, rows: int, Lmax: int, H: int, causal: bool = False,
+                  scale: float = 0.125):
+    assert _ld(kc) == _ld(vc) and len_i32.dtype == torch.int32
+    check(_lib.load().rpo_text_attn_fwd(q.data_ptr(), _ld(q), kc.data_ptr(), vc.data_ptr(), _ld(kc),
+                                        out.data_ptr(), _ld(out), dtype_code(q.dtype), len_i32.data_ptr(), n_cls,
+                                        rows, Lmax, H, int(causal), scale, _stream()), "rpo_text_attn_fwd")
+    return out
+
+
+def text_attn_bwd(q, kc, vc, da, dq, len_i32, n_cls: int, rows: int, Lmax: int, H: int, scale: float = 0.125):
+    assert _ld(kc) == _ld(vc) and len_i32.dtype == torch.int32
+    check(_lib.load().rpo_text_attn_bwd(q.data_ptr(), _ld(q), kc.data_ptr(), vc.data_ptr(), _ld(kc),
+                                        da.data_ptr(), _ld(da), dq.data_ptr(), _ld(dq), dtype_code(q.dtype),
+                                        len_i32.data_ptr(), n_cls, rows, Lmax, H, scale, _stream()),
+          "rpo_text_attn_bwd")
+    return dq
+
+
+def head_workspace_floats(B: int, Cc: int, K: int, e: int) -> int:
+    return int(_lib.load().rpo_head_workspace_floats(B, Cc, K, e))
+
+
+def head_fwd_bwd(img_f, text_f, label, scale_exp: float, logits, loss, d_img_f, d_text_f, ws):
+    B, K, e = img_f.shape
+    Cc = text_f.shape[0]
+    assert img_f.is_contiguous() and text_f.is_contiguous() and logits.is_contiguous()
+    assert label is None or label.dtype == torch.int64
+    check(_lib.load().rpo_head_fwd_bwd(img_f.data_ptr(), text_f.data_ptr(), _p(label), scale_exp,
+                                       logits.data_ptr(), _p(loss), _p(d_img_f), _p(d_text_f), B, Cc, K, e,
+                                       ws.data_ptr(), _stream()), "rpo_head_fwd_bwd")
+    return logits
+
+
+def sgd_step(p, g, buf, lr: float, momentum: float, wd: float, grad_scale: float, first_step: bool):
+    assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
+    check(_lib.load().rpo_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, wd,
+                                   grad_scale, int(first_step), _stream()), "rpo_sgd_step")
+    return p
+
+
+def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    assert src.dtype == torch.float32 and src.shape == dst.shape
+    check(_lib.load().rpo_convert(src.data_ptr(), _ld(src), dst.data_ptr(), dtype_code(dst.dtype), _ld(dst),
+                                  src.shape[0], src.shape[1], _stream()), "rpo_convert")
+    return dst
+
+
+def probe_mfma(which: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    d = torch.empty(32, 32, dtype=torch.float32, device=a.device)
+    check(_lib.load().rpo_probe_mfma(which, a.data_ptr(), b.data_ptr(), d.data_ptr(), _stream()),
+          "rpo_probe_mfma")
+    return d

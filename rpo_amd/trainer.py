@@ -1,0 +1,170 @@
+"""``RPO`` trainer step with the reference's surface (trainers/rpo.py:235-357).
+
+Only the step semantics are reproduced -- Dassl's loop/data manager are out of
+scope: ``forward_backward(batch)`` runs
+forward -> zero-grad -> backward -> SGD step (:306-309), returns
+``{"loss": float}`` (:311) and updates the learning rate after the last batch
+of an epoch (:313-314).  The whole forward+backward is one captured HIP graph
+replay; the optimiser is the library's fused SGD kernel; in data-parallel runs a
+single RCCL all-reduce of the flat gradient buffer sits between the two.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import RPOConfig
+from .custom_clip import CustomCLIP
+from .dist import GradSync
+
+
+@dataclass
+class OptimConfig:
+    """configs/trainers/RPO/main_K24.yaml:15-22.  momentum / weight_decay are Dassl's
+    defaults (un-vendored; 0.9 / 5e-4 upstream) and therefore explicit here."""
+    lr: float = 0.01
+    max_epoch: int = 15
+    lr_scheduler: str = "cosine"
+    warmup_epoch: int = 1
+    warmup_type: str = "constant"
+    warmup_cons_lr: float = 1e-5
+    momentum: float = 0.9
+    weight_decay: float = 5e-4
+
+
+def lr_at_epoch(oc: OptimConfig, epoch: int) -> float:
+    """LR in force during 0-based ``epoch``: constant warm-up, then cosine annealing evaluated
+    at the global epoch index (Dassl ConstantWarmupScheduler over CosineAnnealingLR(T_max=max_epoch))."""
+    if epoch < oc.warmup_epoch and oc.warmup_type == "constant":
+        return oc.warmup_cons_lr
+    if oc.lr_scheduler == "cosine":
+        return 0.5 * oc.lr * (1.0 + math.cos(math.pi * epoch / oc.max_epoch))
+    return oc.lr
+
+
+class RPO:
+    def __init__(self, cfg: RPOConfig, state_dict: Dict[str, np.ndarray], tokens: Optional[np.ndarray] = None,
+                 optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
+                 act_dtype: torch.dtype = torch.bfloat16, batch_size: int = 4, num_batches: int = 1,
+                 use_graph: bool = True, sync: Optional[GradSync] = None, prompts=None):
+        self.cfg = cfg
+        self.optim_cfg = optim or OptimConfig()
+        self.device = torch.device(device)
+        self.batch_size = batch_size
+        self.num_batches = num_batches
+        self.sync = sync or GradSync(init=False)
+        self.use_graph = use_graph
+        self.epoch = 0
+        self.batch_idx = 0
+        self._steps = 0
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self.build_model(state_dict, tokens, act_dtype, prompts)
+
+    # trainers/rpo.py:240-288
+    def build_model(self, state_dict, tokens, act_dtype, prompts) -> None:
+        self.model = CustomCLIP(self.cfg, state_dict, tokens, self.device, act_dtype,
+                                max_batch=self.batch_size, prompts=prompts)
+        self.engine = self.model.engine
+        self.lr = lr_at_epoch(self.optim_cfg, 0)
+        cfg = self.cfg
+        self._image = torch.zeros(self.batch_size, 3, cfg.image_size, cfg.image_size, device=self.device)
+        self._label = torch.zeros(self.batch_size, dtype=torch.int64, device=self.device)
+        if self.sync.enabled:                       # identical prompts on every rank
+            self.sync.broadcast(self.engine.params)
+
+    def parse_batch_train(self, batch):
+        """trainers/rpo.py:318-323."""
+        return (batch["img"].to(self.device, dtype=torch.float32, non_blocking=True),
+                batch["label"].to(self.device, dtype=torch.int64, non_blocking=True))
+
+    def _capture(self) -> None:
+        eng = self.engine
+        eng.forward_backward(self._image, self._label)          # eager warm-up: sets kernel attributes,
+        torch.cuda.synchronize()                                # builds the text K/V cache
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.forward_backward(self._image, self._label)
+        self._graph = g
+
+    def forward_backward(self, batch) -> Dict[str, float]:
+        """trainers/rpo.py:290-316."""
+        image, label = self.parse_batch_train(batch)
+        loss = self.step_async(image, label)
+        summary = {"loss": float(loss.item())}                  # D2H sync, as the reference (:311)
+        if (self.batch_idx + 1) == self.num_batches:
+            self.update_lr()
+            self.batch_idx = 0
+        else:
+            self.batch_idx += 1
+        return summary
+
+    def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """One optimisation step, nothing synchronised; returns the device loss scalar."""
+        eng, oc = self.engine, self.optim_cfg
+        assert image.shape[0] == self.batch_size, "graph path needs the configured batch size"
+        self._image.copy_(image, non_blocking=True)
+        self._label.copy_(label, non_blocking=True)
+        if self.use_graph:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            eng.forward_backward(self._image, self._label)
+        self.sync.all_reduce_sum(eng.grads)
+        ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
+                     self.sync.grad_scale, first_step=(self._steps == 0))
+        self._steps += 1
+        return eng.loss
+
+    def update_lr(self) -> None:
+        self.epoch += 1
+        self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+
+    # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
+    @torch.no_grad()
+    def model_inference(self, image: torch.Tensor) -> torch.Tensor:
+        self.model.prompt_learner.eval()
+        try:
+            return self.model(image)
+        finally:
+            self.model.prompt_learner.train()
+
+    # -- checkpoints: Dassl layout <dir>/prompt_learner/model.pth.tar-<epoch> ----------------
+    def save_model(self, directory: str, epoch: Optional[int] = None) -> str:
+        epoch = self.epoch if epoch is None else epoch
+        path = os.path.join(directory, "prompt_learner")
+        os.makedirs(path, exist_ok=True)
+        fn = os.path.join(path, f"model.pth.tar-{epoch}")
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.prompt_learner.state_dict().items()}
+        torch.save({"state_dict": sd, "epoch": epoch, "momentum": self.engine.mom.cpu(),
+                    "steps": self._steps}, fn)
+        return fn
+
+    def load_model(self, directory: str, epoch: Optional[int] = None) -> None:
+        """trainers/rpo.py:325-357."""
+        if not directory:
+            print("Note that load_model() is skipped as no pretrained model is given")
+            return
+        model_file = "model-best.pth.tar" if epoch is None else f"model.pth.tar-{epoch}"
+        model_path = os.path.join(directory, "prompt_learner", model_file)
+        if not os.path.exists(model_path):
+            raise FileNotFoundError(f'Model not found at "{model_path}"')
+        ck = torch.load(model_path, map_location="cpu", weights_only=False)
+        sd = ck["state_dict"]
+        for k in ("token_prefix", "token_suffix"):
+            sd.pop(k, None)
+        with torch.no_grad():
+            for name, p in self.model.prompt_learner.named_parameters():
+                if name in sd:
+                    p.copy_(sd[name].to(p.dtype))
+        if "momentum" in ck:
+            self.engine.mom.copy_(ck["momentum"])
+            self._steps = int(ck.get("steps", 1))
+        self.epoch = int(ck.get("epoch", 0))
+        self.lr = lr_at_epoch(self.optim_cfg, self.epoch)

@@ -1,0 +1,187 @@
+"""End-to-end parity on the MI355X: CustomCLIP / RPO (HIP path, through the C ABI)
+against the golden vectors captured from the REAL reference (tests/golden/) and
+against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): logits and learned prompts within 1e-3 of
+the reference in fp32.  The f32 mode is asserted at 1e-3 absolute on logits / loss /
+updated prompts and 1e-3 relative-to-max on gradients (measured ~1e-5).
+The bf16 throughput mode cannot meet 1e-3 at logit scale 100;
+it is asserted at a documented looser bound and its measured error is printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import CASES, load_golden, workload  # noqa: E402
+from rpo_amd import synth  # noqa: E402
+
+TOL_F32 = 1e-3
+BF16_LOGIT_ATOL = 0.35         # logits are O(1..8) at scale 100
+BF16_GRAD_REL = 0.12           # relative to max |grad|
+
+
+def _model(tag, act, max_batch=None):
+    from rpo_amd.custom_clip import CustomCLIP
+    cfg, sd, toks, tp, ip, image, label = workload(tag)
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=max_batch or image.shape[0], prompts=(tp, ip))
+    return m, torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda()
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_f32_matches_reference_golden(tag):
+    g = load_golden(tag)
+    m, image, label = _model(tag, torch.float32)
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() <= TOL_F32
+    m.prompt_learner.train()
+    loss = m(image, label)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= TOL_F32
+    gt = m.prompt_learner.text_prompt.grad.cpu().numpy()
+    gi = m.prompt_learner.img_prompt.grad.cpu().numpy()
+    rt, ri = _relmax(gt, g["g_text"]), _relmax(gi, g["g_img"])
+    print(f"[f32 {tag}] logits err {np.abs(logits - g['logits']).max():.2e} loss err "
+          f"{abs(loss.item() - float(g['loss'])):.2e} g_text rel {rt:.2e} g_img rel {ri:.2e}")
+    assert rt <= TOL_F32 and ri <= TOL_F32
+
+
+def test_f32_prompt_rows_per_block():
+    """Bisecting aid: prompt rows after every block vs the reference's forward hooks."""
+    tag = "d2_k8_b3"
+    g = load_golden(tag)
+    m, image, label = _model(tag, torch.float32)
+    eng, cfg = m.engine, m.cfg
+    eng.forward_backward(image, label)
+    torch.cuda.synchronize()
+    B, N, K = image.shape[0], cfg.n_frozen, cfg.K
+    for l in range(cfg.layers_v):
+        rows = eng.x[l + 1][B * N:B * (N + K)].view(B, K, cfg.d_v).cpu().numpy()
+        assert np.abs(rows - g["img_rows"][l]).max() <= TOL_F32, f"image block {l}"
+    for l in range(cfg.layers_t):
+        rows = eng.xt[l + 1].view(cfg.n_cls, K, cfg.d_t).cpu().numpy()
+        assert np.abs(rows - g["text_rows"][l]).max() <= TOL_F32, f"text block {l}"
+
+
+@pytest.mark.parametrize("tag", ["d2_k8_b3", "d12_k24_b4"])
+def test_f32_sgd_steps_match_reference(tag):
+    from rpo_amd.trainer import RPO, OptimConfig
+    g = load_golden(tag)
+    cfg, sd, toks, tp, ip, _, _ = workload(tag)
+    B = CASES[tag][2]
+    lr, mom, wd = (float(v) for v in g["sgd_hparams"])
+    oc = OptimConfig(lr=lr, momentum=mom, weight_decay=wd, warmup_epoch=0, lr_scheduler="constant")
+    tr = RPO(cfg, sd, toks, oc, "cuda:0", torch.float32, batch_size=B, num_batches=10 ** 9, prompts=(tp, ip))
+    losses = []
+    for step in range(4):
+        batch = {"img": torch.from_numpy(synth.images(cfg, B, seed=1234 + 10 * step)),
+                 "label": torch.from_numpy(synth.labels(cfg, B, seed=4321 + 10 * step))}
+        losses.append(tr.forward_backward(batch)["loss"])
+        if step in (0, 3):
+            t = tr.model.prompt_learner.text_prompt.detach().cpu().numpy()
+            i = tr.model.prompt_learner.img_prompt.detach().cpu().numpy()
+            assert np.abs(t - g[f"text_prompt_step{step + 1}"]).max() <= TOL_F32
+            assert np.abs(i - g[f"img_prompt_step{step + 1}"]).max() <= TOL_F32
+    assert np.abs(np.asarray(losses) - g["sgd_losses"]).max() <= TOL_F32
+
+
+@pytest.mark.parametrize("tag", ["d2_k8_b3", "d12_k24_b4"])
+def test_bf16_error_is_bounded_and_reported(tag):
+    g = load_golden(tag)
+    m, image, label = _model(tag, torch.bfloat16)
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    m.prompt_learner.train()
+    loss = m(image, label)
+    loss.backward()
+    gt = m.prompt_learner.text_prompt.grad.cpu().numpy()
+    gi = m.prompt_learner.img_prompt.grad.cpu().numpy()
+    le = np.abs(logits - g["logits"]).max()
+    rt, ri = _relmax(gt, g["g_text"]), _relmax(gi, g["g_img"])
+    print(f"[bf16 {tag}] logits err {le:.3e} loss err {abs(loss.item() - float(g['loss'])):.3e} "
+          f"g_text rel {rt:.3e} g_img rel {ri:.3e}")
+    assert np.isfinite(logits).all() and le <= BF16_LOGIT_ATOL
+    assert rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL
+    assert (logits.argmax(-1) == g["logits"].argmax(-1)).mean() >= 0.5
+
+
+@pytest.mark.parametrize("act", [torch.float32, torch.bfloat16])
+def test_graph_replay_equals_eager(act):
+    from rpo_amd.trainer import RPO
+    tag = "d2_k8_b3"
+    cfg, sd, toks, tp, ip, image, label = workload(tag)
+    B = image.shape[0]
+    outs = []
+    for use_graph in (False, True):
+        tr = RPO(cfg, sd, toks, None, "cuda:0", act, batch_size=B, use_graph=use_graph, prompts=(tp, ip))
+        ls = []
+        for step in range(3):
+            batch = {"img": torch.from_numpy(synth.images(cfg, B, seed=50 + step)),
+                     "label": torch.from_numpy(synth.labels(cfg, B, seed=60 + step))}
+            ls.append(tr.forward_backward(batch)["loss"])
+        outs.append((ls, tr.engine.params.clone()))
+    assert outs[0][0] == outs[1][0], "graph replay must be bit-identical to eager launches"
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_ragged_and_max_length_classes_f32():
+    """len_c from 3 up to the maximum 77-K, 5 classes; vs the dense CPU oracle."""
+    from oracle.rpo_oracle import OracleRPO
+    from rpo_amd.config import vit_b16
+    from rpo_amd.custom_clip import CustomCLIP
+    cfg = vit_b16(layers_v=1, layers_t=2, K=6, n_cls=5)
+    toks = synth.synthetic_tokens(cfg, [3, 71, 20, 8, 71])
+    sd = synth.clip_state_dict(cfg, seed=3, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=11)
+    image, label = synth.images(cfg, 2), synth.labels(cfg, 2)
+    o = OracleRPO(sd, toks, cfg.K, cfg.patch)
+    o.set_prompts(tp, ip)
+    out, gt, gi = o.loss_and_grads(image, label)
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float32, max_batch=2, prompts=(tp, ip))
+    loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    loss.backward()
+    assert abs(loss.item() - out.loss.item()) <= TOL_F32
+    assert _relmax(m.prompt_learner.text_prompt.grad.cpu().numpy(), gt.numpy()) <= TOL_F32
+    assert _relmax(m.prompt_learner.img_prompt.grad.cpu().numpy(), gi.numpy()) <= TOL_F32
+
+
+def test_smaller_batch_than_max_and_linearity():
+    """Size-independent property at full width: the loss gradient is linear in the per-image
+    losses, so g(batch of 4) == mean of g(each image alone) (mean-CE)."""
+    tag = "d2_k8_b3"
+    cfg, sd, toks, tp, ip, _, _ = workload(tag)
+    from rpo_amd.custom_clip import CustomCLIP
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float32, max_batch=4, prompts=(tp, ip))
+    img = torch.from_numpy(synth.images(cfg, 4, seed=5)).cuda()
+    lab = torch.from_numpy(synth.labels(cfg, 4, seed=6)).cuda()
+    m.engine.forward_backward(img, lab)
+    g_all = m.engine.grads.clone()
+    acc = torch.zeros_like(g_all)
+    for b in range(4):
+        m.engine.forward_backward(img[b:b + 1].contiguous(), lab[b:b + 1].contiguous())
+        acc += m.engine.grads
+    torch.cuda.synchronize()
+    assert (acc / 4 - g_all).abs().max().item() <= 1e-5 * max(1.0, g_all.abs().max().item())
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from rpo_amd.trainer import RPO
+    tag = "d1_k4_b2"
+    cfg, sd, toks, tp, ip, image, label = workload(tag)
+    tr = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=(tp, ip))
+    tr.forward_backward({"img": torch.from_numpy(image), "label": torch.from_numpy(label)})
+    fn = tr.save_model(str(tmp_path), epoch=3)
+    ck = torch.load(fn, map_location="cpu", weights_only=False)
+    assert set(ck["state_dict"]) == {"text_prompt", "img_prompt"} and ck["epoch"] == 3
+    tr2 = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=(tp, ip))
+    tr2.load_model(str(tmp_path), epoch=3)
+    assert torch.equal(tr2.engine.params, tr.engine.params)
+    a = tr.model_inference(torch.from_numpy(image).cuda())
+    b = tr2.model_inference(torch.from_numpy(image).cuda())
+    assert torch.equal(a, b)

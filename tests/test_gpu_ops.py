@@ -1,0 +1,296 @@
+"""Op-level parity on the MI355X: every C-ABI kernel against its CPU oracle
+(oracle/rows_oracle.py, float64) on seeded inputs, both storage modes.
+
+Tolerances (written here, asserted below):
+  f32 mode : max|err| <= 2e-5 * max|ref|   (exact-f32 MFMA; only summation order differs)
+  bf16 mode: max|err| <= 1.5e-2 * max|ref| (inputs are pre-rounded to bf16 so the error
+             budget is the bf16 rounding of outputs / of P inside attention)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rows_oracle as R  # noqa: E402  (checker only)
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f32": 2e-5, "bf16": 1.5e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32) * scale
+
+
+def q(t, mode):
+    """value the kernel will actually see, as float64 on the CPU"""
+    return t.to(DT[mode]).to(torch.float64)
+
+
+def close(got, ref, mode, what, tol=None):
+    got = got.detach().to(torch.float64).cpu()
+    ref = ref.to(torch.float64)
+    err = (got - ref).abs().max().item()
+    den = max(ref.abs().max().item(), 1e-30)
+    lim = (tol if tol is not None else TOL[mode])
+    assert math.isfinite(err) and err <= lim * den, f"{what} [{mode}]: max err {err:.3e} vs max ref {den:.3e} (rel {err/den:.2e} > {lim})"
+
+
+def ops():
+    from rpo_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------
+def test_library_loads_and_probe_layouts():
+    """The fragment layouts every MFMA kernel assumes, checked on the device with an
+    ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
+    o = ops()
+    assert o.version() == 1
+    for which, kdim in ((0, 16), (1, 2)):
+        g = torch.Generator().manual_seed(which)
+        a = torch.randint(-4, 5, (32, kdim), generator=g).float()
+        b = torch.randint(-4, 5, (32, kdim), generator=g).float() + torch.arange(32).float()[:, None] % 3
+        d = o.probe_mfma(which, a.to(dev()), b.to(dev())).cpu()
+        assert torch.equal(d, a @ b.t()), f"MFMA layout probe {which} failed"
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(130, 260, 128), (333, 768, 768), (64, 128, 3072)])
+def test_gemm_epilogues(mode, M, N, K):
+    from rpo_amd import _lib as L
+    o = ops()
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias, resid, u = rnd((N,), 3), rnd((M, N), 4), rnd((M, N), 5)
+    a64, w64 = q(a, mode), q(w, mode)
+    acc = a64 @ w64.t()
+    ad, wd = a.to(dev(), DT[mode]), w.to(dev(), DT[mode])
+    bd, rd, ud = bias.to(dev()), resid.to(dev()), u.to(dev())
+    act = DT[mode]
+
+    out = torch.empty(M, N, dtype=act, device=dev())
+    close(o.gemm_nt(ad, wd, out, L.EPI_NONE), acc, mode, "gemm none")
+    close(o.gemm_nt(ad, wd, out, L.EPI_BIAS, bias=bd), acc + bias.double(), mode, "gemm bias")
+    of = torch.empty(M, N, dtype=torch.float32, device=dev())
+    close(o.gemm_nt(ad, wd, of, L.EPI_NONE), acc, mode, "gemm none f32-out", tol=TOL["f32"] if mode == "f32" else 1e-4)
+    close(o.gemm_nt(ad, wd, of, L.EPI_BIAS_RESID, bias=bd, resid=rd), acc + bias.double() + resid.double(), mode,
+          "gemm resid", tol=TOL["f32"] if mode == "f32" else 1e-4)
+    # QuickGELU with the pre-activation of the bottom rows saved
+    row0 = M // 3
+    aux = torch.full((M - row0, N), float("nan"), device=dev())
+    pre = acc + bias.double()
+    close(o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0), R.qgelu(pre), mode, "gemm qgelu")
+    close(aux, pre[row0:], mode, "gemm qgelu saved u", tol=TOL["f32"] if mode == "f32" else 1e-4)
+    close(o.gemm_nt(ad, wd, out, L.EPI_QGELU_BWD, aux=ud), acc * R.qgelu_grad(u.double()), mode, "gemm qgelu bwd")
+    # skipped rectangle must stay untouched, the rest must be computed
+    out.fill_(7.0)
+    sr, sc = 128, 128
+    o.gemm_nt(ad, wd, out, L.EPI_BIAS, bias=bd, skip_row0=sr, skip_col0=sc)
+    ref = acc + bias.double()
+    got = out.double().cpu()
+    if M > sr and N > sc:
+        assert torch.all(got[sr:, sc:] == 7.0)
+    close(got[:sr], ref[:sr], mode, "gemm skip (top)")
+    close(got[:, :sc], ref[:, :sc], mode, "gemm skip (left)")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("patch,size", [(16, 64), (14, 56)])
+def test_patch_embed_matches_conv(mode, patch, size):
+    from rpo_amd import _lib as L
+    o = ops()
+    B, d = 3, 256
+    g = size // patch
+    npatch = g * g
+    img, w = rnd((B, 3, size, size), 1), rnd((d, 3, patch, patch), 2, 0.05)
+    pos, cls, prm = rnd((npatch + 1, d), 3), rnd((d,), 4), rnd((5, d), 5)
+    kmult = 64 if mode == "bf16" else 32
+    kp = (3 * patch * patch + kmult - 1) // kmult * kmult
+    cols = torch.full((B * npatch, kp), float("nan"), dtype=DT[mode], device=dev())
+    o.im2col_patches(img.to(dev()), cols, patch)
+    wp = torch.zeros(d, kp)
+    wp[:, :3 * patch * patch] = w.reshape(d, -1)
+    N, Kp = npatch + 1, 5
+    x = torch.full((B * (N + Kp), d), float("nan"), device=dev())
+    o.gemm_nt(cols, wp.to(dev(), DT[mode]), x, L.EPI_PATCH, resid=pos.to(dev()), group=npatch)
+    o.img_assemble(x, cls.to(dev()), pos.to(dev()), prm.to(dev()), B, N, Kp)
+    conv = torch.nn.functional.conv2d(q(img, mode), q(w, mode), stride=patch)
+    emb = conv.reshape(B, d, -1).permute(0, 2, 1)
+    ref = torch.cat([cls.double().repeat(B, 1, 1), emb], 1) + pos.double()
+    ref = torch.cat([ref.reshape(B * N, d), prm.double().repeat(B, 1)], 0)
+    close(x, ref, mode, "patch embed + assemble", tol=TOL["f32"] if mode == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("d", [512, 768, 1024])
+def test_layernorm_fwd_bwd(d):
+    o = ops()
+    rows = 37
+    x, w, b = rnd((rows, d), 1, 2.0) + 0.3, rnd((d,), 2, 0.1) + 1.0, rnd((d,), 3, 0.05)
+    dy, dres = rnd((rows, d), 4), rnd((rows, d), 5)
+    xd = x.to(dev())
+    for mode in ("f32", "bf16"):
+        y = torch.empty(rows, d, dtype=DT[mode], device=dev())
+        o.layernorm_fwd(xd, w.to(dev()), b.to(dev()), y)
+        close(y, R.ln_fwd(x.double(), w.double(), b.double()), mode, f"ln fwd d={d}",
+              tol=2e-6 if mode == "f32" else 8e-3)
+        dyq = dy.to(DT[mode])
+        dx = torch.empty(rows, d, device=dev())
+        dxc = torch.empty(rows, d, dtype=DT[mode], device=dev())
+        o.layernorm_bwd(dyq.to(dev()), xd, w.to(dev()), dres.to(dev()), dx, dxc)
+        ref = dres.double() + R.ln_bwd(dyq.double(), x.double(), w.double())
+        close(dx, ref, "f32", f"ln bwd d={d} dy={mode}", tol=5e-6)
+        close(dxc, ref, mode, f"ln bwd cast d={d}", tol=5e-6 if mode == "f32" else 8e-3)
+        o.layernorm_bwd(dyq.to(dev()), xd, w.to(dev()), None, dx, None)
+        close(dx, R.ln_bwd(dyq.double(), x.double(), w.double()), "f32", "ln bwd no-resid", tol=5e-6)
+    # in-place fp32 (ln_pre)
+    xin = xd.clone()
+    o.layernorm_fwd(xin, w.to(dev()), b.to(dev()), xin)
+    close(xin, R.ln_fwd(x.double(), w.double(), b.double()), "f32", "ln in-place", tol=2e-6)
+
+
+def _img_rows(B, N, Kp, d, seed):
+    """token matrix in the engine's row layout + per-image views"""
+    t = rnd((B * (N + Kp), 3 * d), seed, 1.0)
+    return t
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,N,Kp", [(2, 3, 197, 24), (1, 2, 50, 7), (2, 1, 257, 48), (1, 1, 5, 0), (1, 2, 224, 40)])
+def test_attn_readonly_fwd(mode, B, H, N, Kp):
+    o = ops()
+    d = 64 * H
+    qkv = _img_rows(B, N, Kp, d, 11)
+    qkv[:, :d] *= 1.5                      # sharper softmax
+    t = qkv.to(dev(), DT[mode])
+    out = torch.full((B * (N + Kp), d), float("nan"), dtype=DT[mode], device=dev())
+    o.attn_readonly_fwd(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], out, B, H, N, Kp)
+    q64 = q(qkv, mode)
+    ref = torch.empty(B * (N + Kp), d, dtype=torch.float64)
+    for b in range(B):
+        fr = slice(b * N, (b + 1) * N)
+        pr = slice(B * N + b * Kp, B * N + (b + 1) * Kp)
+        k, v = q64[fr, d:2 * d], q64[fr, 2 * d:]
+        ref[fr] = R.attn_rows_fwd(q64[fr, :d], k, v, H)
+        if Kp:
+            ref[pr] = R.attn_rows_fwd(q64[pr, :d], k, v, H)
+    close(out, ref, mode, f"attn fwd B{B} H{H} N{N} K{Kp}")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,N,Kp", [(2, 3, 197, 24), (1, 2, 50, 7), (2, 1, 257, 48), (1, 1, 197, 33)])
+def test_attn_readonly_bwd(mode, B, H, N, Kp):
+    o = ops()
+    d = 64 * H
+    qkv = _img_rows(B, N, Kp, d, 12)
+    da = rnd((B * Kp, d), 13)
+    t = qkv.to(dev(), DT[mode])
+    dq = torch.full((B * Kp, d), float("nan"), dtype=DT[mode], device=dev())
+    Rf = B * N
+    o.attn_readonly_bwd(t[Rf:, :d], t[:Rf, d:2 * d], t[:Rf, 2 * d:], da.to(dev(), DT[mode]), dq, B, H, N, Kp)
+    q64, da64 = q(qkv, mode), q(da, mode)
+    ref = torch.empty(B * Kp, d, dtype=torch.float64)
+    for b in range(B):
+        fr = slice(b * N, (b + 1) * N)
+        pr = slice(Rf + b * Kp, Rf + (b + 1) * Kp)
+        ref[b * Kp:(b + 1) * Kp] = R.attn_rows_bwd(q64[pr, :d], q64[fr, d:2 * d], q64[fr, 2 * d:],
+                                                   da64[b * Kp:(b + 1) * Kp], H)
+    close(dq, ref, mode, f"attn bwd B{B} H{H} N{N} K{Kp}", tol=None if mode == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_text_attn_fwd_bwd(mode):
+    o = ops()
+    lens = [3, 71, 20, 8, 10]
+    n, H, Kr, Lmax = len(lens), 2, 6, 71
+    d = 64 * H
+    kv = rnd((n * Lmax, 2 * d), 21)
+    qr, da = rnd((n * Kr, d), 22, 1.5), rnd((n * Kr, d), 23)
+    kvd = kv.to(dev(), DT[mode])
+    len_d = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = torch.full((n * Kr, d), float("nan"), dtype=DT[mode], device=dev())
+    dq = torch.full((n * Kr, d), float("nan"), dtype=DT[mode], device=dev())
+    o.text_attn_fwd(qr.to(dev(), DT[mode]), kvd[:, :d], kvd[:, d:], out, len_d, n, Kr, Lmax, H, causal=False)
+    o.text_attn_bwd(qr.to(dev(), DT[mode]), kvd[:, :d], kvd[:, d:], da.to(dev(), DT[mode]), dq, len_d, n, Kr, Lmax, H)
+    kv64, q64, da64 = q(kv, mode), q(qr, mode), q(da, mode)
+    rf, rb = torch.empty(n * Kr, d, dtype=torch.float64), torch.empty(n * Kr, d, dtype=torch.float64)
+    for c, L in enumerate(lens):
+        k, v = kv64[c * Lmax:c * Lmax + L, :d], kv64[c * Lmax:c * Lmax + L, d:]
+        sl = slice(c * Kr, (c + 1) * Kr)
+        rf[sl] = R.attn_rows_fwd(q64[sl], k, v, H)
+        rb[sl] = R.attn_rows_bwd(q64[sl], k, v, da64[sl], H)
+    close(out, rf, mode, "text attn fwd", tol=None if mode == "f32" else 8e-3)
+    close(dq, rb, mode, "text attn bwd", tol=None if mode == "f32" else 8e-3)
+    # causal pass over the frozen tokens: packed [n*Lmax, 3d]
+    qkv = rnd((n * Lmax, 3 * d), 24)
+    t = qkv.to(dev(), DT[mode])
+    outc = torch.full((n * Lmax, d), float("nan"), dtype=DT[mode], device=dev())
+    o.text_attn_fwd(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], outc, len_d, n, Lmax, Lmax, H, causal=True)
+    q3 = q(qkv, mode)
+    for c, L in enumerate(lens):
+        sl = slice(c * Lmax, c * Lmax + L)
+        ref = R.attn_causal_fwd(q3[sl, :d], q3[sl, d:2 * d], q3[sl, 2 * d:], H, torch.arange(1, L + 1))
+        close(outc[sl], ref, mode, f"text causal attn class {c}", tol=None if mode == "f32" else 8e-3)
+
+
+@pytest.mark.parametrize("B,C,K,e", [(4, 19, 24, 512), (3, 300, 4, 768), (1, 2, 1, 64)])
+def test_head_fwd_bwd(B, C, K, e):
+    o = ops()
+    i_f, t_f = rnd((B, K, e), 31), rnd((C, K, e), 32)
+    lab = torch.tensor([(7 * b + 1) % C for b in range(B)])
+    lg, ls, di, dt = R.head_fwd_bwd(i_f.double(), t_f.double(), lab, 100.0)
+    logits = torch.empty(B, C, device=dev())
+    loss = torch.empty(1, device=dev())
+    d_i, d_t = torch.empty(B, K, e, device=dev()), torch.empty(C, K, e, device=dev())
+    ws = torch.empty(o.head_workspace_floats(B, C, K, e), device=dev())
+    o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), lab.to(dev()), 100.0, logits, loss, d_i, d_t, ws)
+    close(logits, lg, "f32", "head logits", tol=5e-6)
+    assert abs(loss.item() - ls.item()) <= 5e-6 * max(1.0, abs(ls.item()))
+    close(d_i, di, "f32", "head d_img_f", tol=2e-5)
+    close(d_t, dt, "f32", "head d_text_f", tol=2e-5)
+    logits.zero_()
+    o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), None, 100.0, logits, None, None, None, ws)
+    close(logits, lg, "f32", "head logits (eval)", tol=5e-6)
+
+
+def test_sgd_broadcast_reduce_convert():
+    o = ops()
+    n = 30720
+    p, g = rnd((n,), 41), rnd((n,), 42)
+    pd, gd, buf = p.to(dev()), g.to(dev()), torch.zeros(n, device=dev())
+    rp, rb = p.double(), None
+    for step in range(3):
+        o.sgd_step(pd, gd, buf, 0.01, 0.9, 5e-4, 0.5, first_step=(step == 0))
+        rp, rb = R.sgd(rp, g.double(), rb, 0.01, 0.9, 5e-4, first=(step == 0), grad_scale=0.5)
+    close(pd, rp, "f32", "sgd", tol=1e-6)
+    src = rnd((24, 512), 43)
+    dst = torch.empty(19 * 24, 512, device=dev())
+    o.broadcast_rows(src.to(dev()), dst, 19)
+    assert torch.equal(dst.cpu(), src.repeat(19, 1))
+    big = rnd((32 * 24, 768), 44)
+    out = torch.empty(24, 768, device=dev())
+    o.reduce_groups(big.to(dev()), out, 32)
+    acc = torch.zeros(24, 768)
+    for gidx in range(32):                      # same fixed order as the kernel: bit-exact
+        acc += big[gidx * 24:(gidx + 1) * 24]
+    assert torch.equal(out.cpu(), acc)
+    c = torch.empty(24, 768, dtype=torch.bfloat16, device=dev())
+    o.convert(big[:24].to(dev()), c)
+    assert torch.equal(c.cpu(), big[:24].to(torch.bfloat16))
+
+
+def test_argument_errors_are_reported():
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    a = torch.zeros(8, 48, device=dev())
+    with pytest.raises(RPOLibraryError):
+        o.gemm_nt(a, torch.zeros(16, 48, device=dev()), torch.zeros(8, 16, device=dev()))   # K % 32 != 0
+    with pytest.raises(RPOLibraryError):
+        o.layernorm_fwd(torch.zeros(4, 30, device=dev()), torch.zeros(30, device=dev()),
+                        torch.zeros(30, device=dev()), torch.zeros(4, 30, device=dev()))
