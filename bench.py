@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one full RPO train step (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = forward of both towers + cosine-logit head + CE + backward to the two prompt
+tensors + (N > 1) one RCCL all-reduce of the flat prompt-gradient buffer + SGD, on
+synthetic 224x224 batches already resident in HBM.  Workload at
+every N: configs[1] "ViT-B/16 K=24, synthetic 224x224, batch=32 per GPU, bf16" (weak scaling:
+global batch = 32*N, configs[2] at N=8).  Rank 0 prints ONE JSON line.
+
+roofline   : bound mfma; achieved = algorithmic FLOPs of one step launch (mask-aware minimal
+             work, SURVEY.md section 8d: 32 x 42.31 GF + 58.08 GF = 1411.9 GF) / measured step time
+             per GPU, against the 2.5 PFLOP/s dense bf16 MFMA peak.  `dominant_kernel` times the
+             largest GEMM of the step (c_fc + QuickGELU, 7072x3072x768) with HIP events on the
+             launch stream.
+cpu_baseline: the dense CPU oracle (oracle/rpo_oracle.py, same op sequence and cost as the
+             reference's CPU path, validated against it) timed on this host's cores on a bounded
+             sample (B=4, 12 layers, 1 warm-up + 2 timed steps).  Rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from rpo_amd import synth  # noqa: E402
+from rpo_amd.config import flops_image, flops_step, flops_text, vit_b16, vit_l14  # noqa: E402
+from rpo_amd.dist import GradSync  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(cfg, sd, toks, prompts, steps: int = 2, batch: int = 4):
+    """Timed oracle steps on the host CPU (checker code measured as the BASELINE only)."""
+    from oracle.rpo_oracle import OracleRPO, OracleSGD, train_steps
+    nthr = os.cpu_count() or 1
+    torch.set_num_threads(nthr)
+    m = OracleRPO(sd, toks, cfg.K, cfg.patch)
+    m.set_prompts(*prompts)
+    opt = OracleSGD(0.01, 0.9, 5e-4)
+    batches = [(synth.images(cfg, batch, seed=900 + i), synth.labels(cfg, batch, seed=950 + i))
+               for i in range(steps + 1)]
+    train_steps(m, opt, batches[:1])
+    t0 = time.perf_counter()
+    train_steps(m, opt, batches[1:])
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": nthr, "kind": "port",
+            "sample": f"dense fp32 oracle (reference-equivalent op sequence + autograd), {cfg.name} K={cfg.K} "
+                      f"B={batch}, 1 warm-up + {steps} timed steps, torch {torch.__version__} CPU, {nthr} threads",
+            "ms_per_step": round(1e3 * dt / steps, 1)}
+
+
+def time_dominant_kernel(trainer, batch: int, iters: int = 30):
+    """c_fc GEMM + QuickGELU epilogue at the step's own shape, HIP events on the launch stream."""
+    from rpo_amd import ops
+    from rpo_amd._lib import EPI_BIAS_QGELU
+    eng, cfg = trainer.engine, trainer.cfg
+    R = batch * cfg.seq_v
+    blk = eng.vis[0]
+    h, g = eng.h[:R], eng.g[:R]
+    h.normal_()
+    for _ in range(3):
+        ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc, aux=eng.u[0][:batch * cfg.K], aux_row0=batch * cfg.n_frozen)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc, aux=eng.u[0][:batch * cfg.K], aux_row0=batch * cfg.n_frozen)
+    e.record()
+    e.synchronize()
+    us = 1e3 * s.elapsed_time(e) / iters
+    fl = 2.0 * R * 4 * cfg.d_v * cfg.d_v
+    return {"name": f"gemm_nt {eng.act} {R}x{4 * cfg.d_v}x{cfg.d_v} bias+QuickGELU", "avg_us": round(us, 2),
+            "achieved": round(fl / us / 1e6, 1), "unit": "TFLOP/s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--K", type=int, default=24)
+    ap.add_argument("--model", default="ViT-B/16", choices=["ViT-B/16", "ViT-L/14"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    sync = GradSync()                                    # reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
+    if sync.world_size != args.gpus:
+        if args.gpus != 1 and sync.world_size == 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run (one rank per GPU)")
+    dev = torch.device(f"cuda:{sync.local_rank}")
+    torch.cuda.set_device(dev)
+
+    from rpo_amd.trainer import RPO, OptimConfig
+    cfg = (vit_b16 if args.model == "ViT-B/16" else vit_l14)(K=args.K)
+    toks = synth.default_tokens(cfg)
+    lens = synth.len_prompts(toks)
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    prompts = synth.prompts(cfg, sd, seed=7)
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tr = RPO(cfg, sd, toks, OptimConfig(), dev, act, batch_size=args.batch, num_batches=10 ** 9,
+             use_graph=not args.no_graph, sync=sync, prompts=prompts)
+
+    # synthetic batches resident in HBM before the timed region (distinct data per rank and step)
+    pool = 4
+    imgs = [torch.from_numpy(synth.images(cfg, args.batch, seed=1234 + 17 * i, rank=sync.rank)).to(dev) for i in range(pool)]
+    labs = [torch.from_numpy(synth.labels(cfg, args.batch, seed=4321 + 17 * i, rank=sync.rank)).to(dev) for i in range(pool)]
+
+    for i in range(args.warmup):
+        tr.step_async(imgs[i % pool], labs[i % pool])
+    sync.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step_async(imgs[i % pool], labs[i % pool])
+    torch.cuda.synchronize()
+    sync.barrier()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    dt = sync.max_over_ranks(dt_local, dev)
+    last_loss = float(loss.item())
+
+    global_batch = args.batch * sync.world_size
+    ms = 1e3 * dt / args.steps
+    value = global_batch * args.steps / dt
+    fl_step = flops_step(cfg, args.batch, lens)          # per GPU (text tower recomputed on every rank)
+    achieved = fl_step / (dt / args.steps) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+    out = {
+        "metric": "images/sec (train step, ViT-B/16 K=24)" if (args.model, args.K) == ("ViT-B/16", 24)
+        else f"images/sec (train step, {args.model} K={args.K})",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": sync.world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{cfg.name} K={cfg.K}, synthetic {cfg.image_size}x{cfg.image_size}, batch={args.batch}/GPU, "
+                               f"n_cls={cfg.n_cls} (Oxford-Pets base prompts), full train step (fwd+bwd+SGD)",
+                   "global_batch": global_batch, "parallelism": f"dp{sync.world_size}",
+                   "hip_graph": not args.no_graph, "final_loss": round(last_loss, 5)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "algorithmic_gflop_per_step_per_gpu": round(fl_step / 1e9, 2),
+                     "gflop_per_image": round(sum(flops_image(cfg)) / 1e9, 2),
+                     "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2)},
+    }
+    if sync.rank == 0:
+        out["roofline"]["dominant_kernel"] = time_dominant_kernel(tr, args.batch)
+        out["hbm_resident_gb"] = round(tr.engine.hbm_bytes() / 2 ** 30, 2)
+        if sync.world_size == 1 and not args.no_cpu_baseline:
+            full = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+            out["cpu_baseline"] = cpu_baseline(cfg, full, toks, prompts)
+        print(json.dumps(out), flush=True)
+    sync.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,11 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; librpo_hip.so must bind to THAT runtime
+    # (same SONAME as /opt/rocm's) or the two would hold separate device contexts and torch's
+    # pointers/streams would be foreign to our kernels.  Importing torch first makes the dynamic
+    # linker resolve our DT_NEEDED entry to the already-resident copy.
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise RPOLibraryError(
             f"{p} not found: build it with `python -m rpo_amd.build` (hipcc, gfx950). "
