@@ -40,10 +40,34 @@ from rpo_amd.dist import GradSync  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(cfg, sd, toks, prompts, steps: int = 2, batch: int = 4):
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask AND the cgroup CPU quota (the GPU box
+    reports 256 logical CPUs but a container quota far below that; 256 spinning threads on a
+    small quota made one oracle step take minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    try:                                        # cgroup v1
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cfg, sd, toks, prompts, steps: int = 2, batch: int = 4, budget_s: float = 25.0):
     """Timed oracle steps on the host CPU (checker code measured as the BASELINE only)."""
     from oracle.rpo_oracle import OracleRPO, OracleSGD, train_steps
-    nthr = os.cpu_count() or 1
+    nthr = usable_cores()
     torch.set_num_threads(nthr)
     m = OracleRPO(sd, toks, cfg.K, cfg.patch)
     m.set_prompts(*prompts)
@@ -52,7 +76,13 @@ def cpu_baseline(cfg, sd, toks, prompts, steps: int = 2, batch: int = 4):
                for i in range(steps + 1)]
     train_steps(m, opt, batches[:1])
     t0 = time.perf_counter()
-    train_steps(m, opt, batches[1:])
+    done = 0
+    for b in batches[1:]:                       # bounded sample: stop once the time budget is spent
+        train_steps(m, opt, [b])
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    steps = done
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": nthr, "kind": "port",
             "sample": f"dense fp32 oracle (reference-equivalent op sequence + autograd), {cfg.name} K={cfg.K} "

@@ -78,6 +78,10 @@ typedef struct rpo_gemm_args {
   int32_t skip_row0, skip_col0;  /* tiles with all rows >= skip_row0 AND all cols >= skip_col0 are not
                                     computed (K/V of prompt rows are never read); -1 disables      */
   int32_t group;                 /* PATCH: patches per image                                       */
+  int32_t split_k;               /* <= 1: off.  S > 1 (EPI_NONE, fp32 C only): k-range split into S slices,
+                                    slice s writes its partial product to C + s * split_stride; the
+                                    consumer (rpo_layernorm_bwd's dy_splits) adds the slabs in order    */
+  int64_t split_stride;          /* elements between slabs (>= M * ldc)                            */
 } rpo_gemm_args;
 
 int rpo_version(void);
@@ -96,13 +100,15 @@ int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
                       void* y, int64_t ldy, int y_dtype, int rows, int d, float eps, void* stream);
 
 /* dx = dres + dLN(dy; x, gamma)   (frozen affine: no dgamma/dbeta).
- * dy in dy_dtype [rows, d]; x fp32 = the forward input; dres fp32 or NULL;
+ * dy in dy_dtype [rows, d] -- or, with dy_splits = S > 1 (fp32 only), the sum of S slabs
+ * dy + s * dy_split_stride written by a split-K rpo_gemm_nt, added in the order s = 0..S-1;
+ * x fp32 = the forward input; dres fp32 or NULL;
  * dx fp32; dx_cast (optional, may be NULL) receives a copy of dx in cast_dtype
  * (the next GEMM's A operand).  Replaces autograd through clip/model.py:158. */
 int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
                       const float* gamma, const float* dres, int64_t lddres,
                       float* dx, int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast,
-                      int rows, int d, float eps, void* stream);
+                      int rows, int d, float eps, int dy_splits, int64_t dy_split_stride, void* stream);
 
 /* Non-overlapping-patch im2col: img [B,3,H,W] fp32 -> out [B*(H/p)*(W/p), ldo] act dtype, column
  * order (c, ky, kx) = conv1.weight.reshape(d, -1); columns [3*p*p, ldo) are zero-filled.

@@ -32,6 +32,8 @@ class GemmArgs(C.Structure):
         ("aux_row0", c_i32),
         ("skip_row0", c_i32), ("skip_col0", c_i32),
         ("group", c_i32),
+        ("split_k", c_i32),
+        ("split_stride", c_i64),
     ]
 
 
@@ -42,7 +44,7 @@ SIGNATURES = {
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
-                                  c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
+                                  c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "rpo_im2col_patches": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "rpo_img_assemble": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "rpo_broadcast_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),

@@ -60,39 +60,65 @@ __device__ __forceinline__ bf16x8_t join8(uint2 lo, uint2 hi) {
 }
 
 // ---- staging ---------------------------------------------------------------------------
-// rows [0, N) of one (image, head) slice: src + key*ld + (already offset to head), 64 elems
-template <int NT, int NTHREADS>
-__device__ __forceinline__ void stage_rows_bf16(char* dst, const bf16_t* src, int64_t ld, int N, int tid) {
-  for (int id = tid; id < NT * 32 * 8; id += NTHREADS) {
-    const int key = id >> 3, c = id & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (key < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)key * ld + c * 8);
-    *reinterpret_cast<uint4*>(dst + key * 144 + c * 16) = v;
-  }
-}
-template <int NT, int NTHREADS>
-__device__ __forceinline__ void stage_transposed_bf16(char* dst, const bf16_t* src, int64_t ld, int N, int tid) {
+// rows [0, N) of one (image, head) slice: src + key*ld (already offset to the head), 64 elements.
+// All global loads of a pass are issued before the first LDS write (fully unrolled, static
+// register indices): a load-use-per-iteration loop serialises one HBM round trip per iteration
+// and was the dominant cost of these kernels.
+template <int NT, int NTHREADS, bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_bf16(char* dst_rows, char* dst_t, const bf16_t* src, int64_t ld, int N,
+                                           int tid) {
+  constexpr int CHUNKS = NT * 32 * 8;
+  constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
   constexpr int TROW = AL<bf16_t, NT>::TROW;
-  for (int id = tid; id < NT * 32 * 8; id += NTHREADS) {
-    const int key = id >> 3, c = id & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (key < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)key * ld + c * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint4 v[ITERS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bf16_t e = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-      *reinterpret_cast<bf16_t*>(dst + (c * 8 + j) * TROW + key * 2) = e;
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * NTHREADS;
+    const int key = id >> 3, c = id & 7;
+    v[it] = make_uint4(0, 0, 0, 0);
+    if (id < CHUNKS && key < N) v[it] = *reinterpret_cast<const uint4*>(src + (int64_t)key * ld + c * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * NTHREADS;
+    const int key = id >> 3, c = id & 7;
+    if (id < CHUNKS) {
+      if (ROWMAJOR) *reinterpret_cast<uint4*>(dst_rows + key * 144 + c * 16) = v[it];
+      if (TRANSPOSED) {
+        const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16_t e = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+          *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + j) * TROW + key * 2) = e;
+        }
+      }
     }
   }
 }
 template <int NT, int NTHREADS>
 __device__ __forceinline__ void stage_rows_f32(float* dst, const float* src, int64_t ld, int N, int tid) {
-  for (int id = tid; id < NT * 32 * 16; id += NTHREADS) {
-    const int key = id >> 4, c = id & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (key < N) v = *reinterpret_cast<const float4*>(src + (int64_t)key * ld + c * 4);
-    float* d = dst + key * 65 + c * 4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  constexpr int CHUNKS = NT * 32 * 16;
+  constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
+  constexpr int BATCH = 7;
+#pragma unroll 1
+  for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+    float4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int id = tid + (it0 + u) * NTHREADS;
+      const int key = id >> 4, c = id & 15;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id < CHUNKS && key < N) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)key * ld + c * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int id = tid + (it0 + u) * NTHREADS;
+      const int key = id >> 4, c = id & 15;
+      if (id < CHUNKS) {
+        float* d = dst + key * 65 + c * 4;
+        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+      }
+    }
   }
 }
 
@@ -220,8 +246,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
   char* ks = smem;
   char* vs = smem + L::K_BYTES;
   if constexpr (sizeof(T) == 2) {
-    stage_rows_bf16<NT, 512>(ks, kb, ld, N, tid);
-    stage_transposed_bf16<NT, 512>(vs, vb, ld, N, tid);
+    stage_bf16<NT, 512, true, false>(ks, nullptr, kb, ld, N, tid);
+    stage_bf16<NT, 512, false, true>(nullptr, vs, vb, ld, N, tid);
   } else {
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(ks), kb, ld, N, tid);
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(vs), vb, ld, N, tid);
@@ -281,9 +307,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
   char* vs = smem + L::K_BYTES;
   char* kt = smem + 2 * L::K_BYTES;  // bf16 only
   if constexpr (sizeof(T) == 2) {
-    stage_rows_bf16<NT, 256>(ks, kb, ldkv, N, tid);
-    stage_rows_bf16<NT, 256>(vs, vb, ldkv, N, tid);
-    stage_transposed_bf16<NT, 256>(kt, kb, ldkv, N, tid);
+    stage_bf16<NT, 256, true, true>(ks, kt, kb, ldkv, N, tid);   // one pass: K row-major + K^T
+    stage_bf16<NT, 256, true, false>(vs, nullptr, vb, ldkv, N, tid);
   } else {
     stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
     stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);

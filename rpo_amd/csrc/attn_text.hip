@@ -29,11 +29,41 @@ __global__ __launch_bounds__(256) void text_attn_kernel(const T* __restrict__ q,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x / H, h = blockIdx.x % H;
   const int L = min(len[c], Lmax);
-  for (int id = tid; id < L * 64; id += 256) {
-    const int j = id >> 6, d = id & 63;
-    const int64_t off = ((int64_t)c * Lmax + j) * ldkv + h * 64 + d;
-    Kf[j * 65 + d] = ActIO<T>::ld(kc + off);
-    Vf[j * 65 + d] = ActIO<T>::ld(vc + off);
+  // stage K and V head slices as fp32 [L][65]; 16-B global loads, all issued before the LDS writes
+  constexpr int EPC = 16 / sizeof(T);          // elements per 16-B chunk
+  constexpr int CPR = 64 / EPC;                // chunks per key row
+  constexpr int ITERS = 128 * CPR / 256;       // Lmax <= 128
+  uint4 kv[ITERS], vv[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * 256;
+    const int j = id / CPR, cch = id % CPR;
+    if (j < L) {
+      const int64_t off = ((int64_t)c * Lmax + j) * ldkv + h * 64 + cch * EPC;
+      kv[it] = *reinterpret_cast<const uint4*>(kc + off);
+      vv[it] = *reinterpret_cast<const uint4*>(vc + off);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * 256;
+    const int j = id / CPR, cch = id % CPR;
+    if (j < L) {
+      float* kd = Kf + j * 65 + cch * EPC;
+      float* vd = Vf + j * 65 + cch * EPC;
+      const uint32_t kw[4] = {kv[it].x, kv[it].y, kv[it].z, kv[it].w};
+      const uint32_t vw[4] = {vv[it].x, vv[it].y, vv[it].z, vv[it].w};
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kd[2 * e] = __uint_as_float(kw[e] << 16); kd[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
+          vd[2 * e] = __uint_as_float(vw[e] << 16); vd[2 * e + 1] = __uint_as_float(vw[e] & 0xffff0000u);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kd[e] = __uint_as_float(kw[e]); vd[e] = __uint_as_float(vw[e]); }
+      }
+    }
   }
   __syncthreads();
   const int j0 = min(lane, Lmax - 1), j1 = min(lane + 64, Lmax - 1);
@@ -110,6 +140,10 @@ extern "C" int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, con
                                  int Lmax, int H, int causal, float scale, void* stream) {
   if (!q || !kc || !vc || !out || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
   if (Lmax > 128) return RPO_E_SHAPE;
+  {
+    const int esz = dtype == RPO_BF16 ? 2 : 4;
+    if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == RPO_BF16)
     return launch<bf16_t, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
@@ -124,6 +158,10 @@ extern "C" int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, con
                                  void* stream) {
   if (!q || !kc || !vc || !da || !dq || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
   if (Lmax > 128) return RPO_E_SHAPE;
+  {
+    const int esz = dtype == RPO_BF16 ? 2 : 4;
+    if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == RPO_BF16)
     return launch<bf16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);

@@ -16,17 +16,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (quiet bit forced)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// f32 -> bf16, round-to-nearest-even, NaN-preserving: a plain fptrunc to __bf16, which hipcc lowers to
+// gfx950's native v_cvt_pk_bf16_f32 (a hand-rolled integer rounding with a NaN branch costs an
+// exec-mask branch per value in the GEMM epilogues).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 template <typename T> struct ActIO;
 template <> struct ActIO<float> {

@@ -9,9 +9,9 @@
 
 namespace {
 
-constexpr int MAXV = 8;   // float4 per lane: d <= 64 * 4 * 8 = 2048
+constexpr int MAXV = 8;   // float4 per lane: d <= 64 * 4 * 8 = 2048 (kernels are templated on the count)
 
-template <typename TY>
+template <typename TY, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* y, int64_t ldy,
@@ -21,10 +21,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
-  float4 v[MAXV];
+  float4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const float mu = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
   TY* yr = y + (int64_t)row * ldy;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
@@ -66,23 +66,24 @@ template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-template <typename TDY, typename TC>
+template <typename TDY, typename TC, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
                                                      const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, int64_t lddres,
                                                      float* dx, int64_t lddx, TC* dxc, int64_t ldc,
-                                                     int rows, int d, float eps) {
+                                                     int rows, int d, float eps, int splits,
+                                                     int64_t split_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
   const TDY* dyr = dy + (int64_t)row * lddy;
-  float4 v[MAXV], g[MAXV];
+  float4 v[NV], g[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   const float mu = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
@@ -102,11 +103,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
   float sg = 0.f, sgx = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       const float4 w = *reinterpret_cast<const float4*>(gamma + 4 * c);
-      const float4 t = load4f<TDY>(dyr + 4 * c);
+      float4 t = load4f<TDY>(dyr + 4 * c);
+      for (int sp = 1; sp < splits; ++sp) {     // split-K slabs, fixed order
+        const float4 t2 = load4f<TDY>(dyr + (int64_t)sp * split_stride + 4 * c);
+        t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
+      }
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
       g[i] = make_float4(t.x * w.x, t.y * w.y, t.z * w.z, t.w * w.w);
       sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   const float mg = wave_sum(sg) / (float)d;
   const float mgx = wave_sum(sgx) / (float)d;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       float4 o = make_float4(rstd * (g[i].x - mg - v[i].x * mgx), rstd * (g[i].y - mg - v[i].y * mgx),
@@ -141,36 +146,53 @@ extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || ldx % 4 != 0 || ldy % 4 != 0) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((rows + 3) / 4), block(256);
+  const int nv = (d / 4 + 63) / 64;
+#define RPO_LN_FWD(TY, NV)                                                                          \
+  hipLaunchKernelGGL((ln_fwd_kernel<TY, NV>), grid, block, 0, s, x, ldx, gamma, beta, static_cast<TY*>(y), \
+                     ldy, rows, d, eps)
+#define RPO_LN_FWD_NV(TY)                                                                           \
+  do {                                                                                              \
+    if (nv <= 2) RPO_LN_FWD(TY, 2); else if (nv == 3) RPO_LN_FWD(TY, 3);                            \
+    else if (nv == 4) RPO_LN_FWD(TY, 4); else RPO_LN_FWD(TY, 8);                                    \
+  } while (0)
   if (y_dtype == RPO_F32) {
     if (!aligned16(y)) return RPO_E_ALIGN;
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, x, ldx, gamma, beta,
-                       static_cast<float*>(y), ldy, rows, d, eps);
+    RPO_LN_FWD_NV(float);
   } else if (y_dtype == RPO_BF16) {
     if (reinterpret_cast<uintptr_t>(y) % 8) return RPO_E_ALIGN;
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, x, ldx, gamma, beta,
-                       static_cast<bf16_t*>(y), ldy, rows, d, eps);
+    RPO_LN_FWD_NV(bf16_t);
   } else {
     return RPO_E_DTYPE;
   }
+#undef RPO_LN_FWD_NV
+#undef RPO_LN_FWD
   return rpo_launch_status();
 }
 
 extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
                                  const float* gamma, const float* dres, int64_t lddres, float* dx,
                                  int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast, int rows,
-                                 int d, float eps, void* stream) {
+                                 int d, float eps, int dy_splits, int64_t dy_split_stride, void* stream) {
   if (!dy || !x || !gamma || !dx || rows <= 0 || d <= 0) return RPO_E_BADARG;
   if (d % 4 != 0 || d > 64 * 4 * MAXV) return RPO_E_SHAPE;
+  if (dy_splits < 1) dy_splits = 1;
+  if (dy_splits > 1 && (dy_dtype != RPO_F32 || dy_split_stride % 4 != 0)) return RPO_E_SHAPE;
   if (!aligned16(x) || !aligned16(gamma) || !aligned16(dx) || ldx % 4 || lddx % 4 || lddy % 4) return RPO_E_ALIGN;
   if (dres && (!aligned16(dres) || lddres % 4)) return RPO_E_ALIGN;
   if (dx_cast && (reinterpret_cast<uintptr_t>(dx_cast) % 8 || ldcast % 4)) return RPO_E_ALIGN;
   if (reinterpret_cast<uintptr_t>(dy) % (dy_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((rows + 3) / 4), block(256);
-#define RPO_LN_BWD(TDY, TC)                                                                          \
-  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), grid, block, 0, s, static_cast<const TDY*>(dy), lddy, \
-                     x, ldx, gamma, dres, lddres, dx, lddx, static_cast<TC*>(dx_cast), ldcast, rows, \
-                     d, eps)
+  const int nv = (d / 4 + 63) / 64;
+#define RPO_LN_BWD_(TDY, TC, NV)                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC, NV>), grid, block, 0, s, static_cast<const TDY*>(dy), lddy, \
+                     x, ldx, gamma, dres, lddres, dx, lddx, static_cast<TC*>(dx_cast), ldcast, rows,     \
+                     d, eps, dy_splits, dy_split_stride)
+#define RPO_LN_BWD(TDY, TC)                                                                    \
+  do {                                                                                         \
+    if (nv <= 2) RPO_LN_BWD_(TDY, TC, 2); else if (nv == 3) RPO_LN_BWD_(TDY, TC, 3);           \
+    else if (nv == 4) RPO_LN_BWD_(TDY, TC, 4); else RPO_LN_BWD_(TDY, TC, 8);                   \
+  } while (0)
   const bool cast_bf16 = dx_cast != nullptr && cast_dtype == RPO_BF16;
   if (dx_cast != nullptr && cast_dtype != RPO_BF16 && cast_dtype != RPO_F32) return RPO_E_DTYPE;
   if (dy_dtype == RPO_F32) {
@@ -181,5 +203,6 @@ extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, con
     return RPO_E_DTYPE;
   }
 #undef RPO_LN_BWD
+#undef RPO_LN_BWD_
   return rpo_launch_status();
 }

@@ -30,6 +30,9 @@ from ._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH,
 from .config import RPOConfig
 
 SCALE = 1.0 / math.sqrt(64.0)
+# split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
+# d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.
+SPLIT_FC, SPLIT_Q = 8, 4
 
 
 def _round_up(x: int, m: int) -> int:
@@ -134,7 +137,7 @@ class Engine:
         # backward temporaries (prompt rows)
         self.d_img_f = f32(Rp, e)
         self.d_img_f_a = a(Rp, e)
-        self.dy_v = f32(Rp, dv)
+        self.dy_v = f32(max(SPLIT_FC, SPLIT_Q), Rp, dv)
         self.dxa_v, self.dxb_v = f32(Rp, dv), f32(Rp, dv)
         self.dxc_v = a(Rp, dv)
         self.du_v = a(Rp, 4 * dv)
@@ -153,7 +156,7 @@ class Engine:
         self.text_f = f32(Rt, e)
         self.d_text_f = f32(Rt, e)
         self.d_text_f_a = a(Rt, e)
-        self.dy_t = f32(Rt, dt)
+        self.dy_t = f32(max(SPLIT_FC, SPLIT_Q), Rt, dt)
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
         self.du_t = a(Rt, 4 * dt)
@@ -264,13 +267,15 @@ class Engine:
             blk = blocks[l]
             a_in = dxa if self.act == torch.float32 else dxc
             ops.gemm_nt(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l])          # d c_proj, d QuickGELU
-            ops.gemm_nt(du, blk.w_fc_t, dy, EPI_NONE)                             # d c_fc
-            ops.layernorm_bwd(dy, xm[l], blk.ln2_w, dxa, dxb, None if self.act == torch.float32 else dxc)
+            ops.gemm_nt(du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC)   # d c_fc
+            ops.layernorm_bwd(dy[:SPLIT_FC], xm[l], blk.ln2_w, dxa, dxb,
+                              None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
             ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                          # d out_proj
             attn_bwd(l, da, dq)
-            ops.gemm_nt(dq, blk.w_q_t, dy, EPI_NONE)                              # d q-projection
-            ops.layernorm_bwd(dy, x[l], blk.ln1_w, dxb, dxa, None if self.act == torch.float32 else dxc)
+            ops.gemm_nt(dq, blk.w_q_t, dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)   # d q-projection
+            ops.layernorm_bwd(dy[:SPLIT_Q], x[l], blk.ln1_w, dxb, dxa,
+                              None if self.act == torch.float32 else dxc)
         return dxa
 
     def _image_backward(self, B: int) -> None:
@@ -283,8 +288,8 @@ class Engine:
             d_f = self.d_img_f[:Rp]
         else:
             d_f = ops.convert(self.d_img_f[:Rp], self.d_img_f_a[:Rp])
-        ops.gemm_nt(d_f, self.img_proj, self.dy_v[:Rp], EPI_NONE)
-        ops.layernorm_bwd(self.dy_v[:Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
+        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, :Rp], EPI_NONE)
+        ops.layernorm_bwd(self.dy_v[0, :Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
         def attn_bwd(l, da, dq):
@@ -293,7 +298,7 @@ class Engine:
 
         dx = self._rows_backward(self.vis, [t[Rf:R] for t in self.x[:-1]], [t[Rf:R] for t in self.xm],
                                  [t[:Rp] for t in self.u], dxa, dxb, dxc, self.du_v[:Rp], self.da_v[:Rp],
-                                 self.dq_v[:Rp], self.dy_v[:Rp], attn_bwd)
+                                 self.dq_v[:Rp], self.dy_v[:, :Rp], attn_bwd)
         # through ln_pre (rpo.py:206) to the appended prompt rows, then sum over the batch (.repeat, :204)
         ops.layernorm_bwd(dx, self.x_pre[Rf:R], self.ln_pre[0], None, dxb)
         ops.reduce_groups(dxb, self.g_img, B)
@@ -303,8 +308,8 @@ class Engine:
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
         d_f = self.d_text_f if self.act == torch.float32 else ops.convert(self.d_text_f, self.d_text_f_a)
-        ops.gemm_nt(d_f, self.text_proj, self.dy_t, EPI_NONE)
-        ops.layernorm_bwd(self.dy_t, self.xt[-1], self.ln_final[0], None, dxa,
+        ops.gemm_nt(d_f, self.text_proj, self.dy_t[0], EPI_NONE)
+        ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
         def attn_bwd(l, da, dq):

@@ -46,17 +46,25 @@ def version() -> int:
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
             aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
-            group: int = 0, m_rows: Optional[int] = None) -> torch.Tensor:
+            group: int = 0, m_rows: Optional[int] = None, split_k: int = 1) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
-    (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``."""
+    (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
+    ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer."""
     M = a.shape[0] if m_rows is None else m_rows
     N, K = w.shape
     assert a.shape[1] == K and a.dtype == w.dtype
-    args = GemmArgs(A=a.data_ptr(), lda=_ld(a), W=w.data_ptr(), ldw=_ld(w), C=out.data_ptr(), ldc=_ld(out),
+    split_stride = 0
+    if split_k > 1:
+        assert out.dim() == 3 and out.shape[0] == split_k and out.stride(2) == 1
+        split_stride, ldc = out.stride(0), out.stride(1)
+    else:
+        ldc = _ld(out)
+    args = GemmArgs(A=a.data_ptr(), lda=_ld(a), W=w.data_ptr(), ldw=_ld(w), C=out.data_ptr(), ldc=ldc,
                     M=M, N=N, K=K, in_dtype=dtype_code(a.dtype), out_dtype=dtype_code(out.dtype),
                     epilogue=epilogue, bias=_p(bias), resid=_p(resid), ldr=0 if resid is None else _ld(resid),
                     aux=_p(aux), ldaux=0 if aux is None else _ld(aux), aux_row0=aux_row0,
-                    skip_row0=skip_row0, skip_col0=skip_col0, group=group)
+                    skip_row0=skip_row0, skip_col0=skip_col0, group=group, split_k=split_k,
+                    split_stride=split_stride)
     check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
     return out
 
@@ -73,11 +81,16 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: t
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres: Optional[torch.Tensor],
                   dx: torch.Tensor, dx_cast: Optional[torch.Tensor] = None, eps: float = LN_EPS) -> torch.Tensor:
     assert x.dtype == torch.float32 and dx.dtype == torch.float32
+    splits, split_stride = 1, 0
+    if dy.dim() == 3:                       # [S, rows, d] split-K slabs
+        splits, split_stride, lddy = dy.shape[0], dy.stride(0), dy.stride(1)
+    else:
+        lddy = _ld(dy)
     check(_lib.load().rpo_layernorm_bwd(
-        dy.data_ptr(), dtype_code(dy.dtype), _ld(dy), x.data_ptr(), _ld(x), gamma.data_ptr(),
+        dy.data_ptr(), dtype_code(dy.dtype), lddy, x.data_ptr(), _ld(x), gamma.data_ptr(),
         _p(dres), 0 if dres is None else _ld(dres), dx.data_ptr(), _ld(dx), _p(dx_cast),
         RPO_F32 if dx_cast is None else dtype_code(dx_cast.dtype), 0 if dx_cast is None else _ld(dx_cast),
-        x.shape[0], x.shape[1], eps, _stream()), "rpo_layernorm_bwd")
+        x.shape[0], x.shape[1], eps, splits, split_stride, _stream()), "rpo_layernorm_bwd")
     return dx
 
 

@@ -102,6 +102,24 @@ def test_gemm_epilogues(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_gemm_split_k_feeds_layernorm_bwd(mode):
+    """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""
+    from rpo_amd import _lib as L
+    o = ops()
+    M, N, K, S = 200, 512, 2048, 8
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    x, gam, dres = rnd((M, N), 3, 2.0), rnd((N,), 4, 0.1) + 1.0, rnd((M, N), 5)
+    slabs = torch.full((S, M + 8, N), float("nan"), device=dev())[:, :M]      # non-contiguous slabs
+    o.gemm_nt(a.to(dev(), DT[mode]), w.to(dev(), DT[mode]), slabs, L.EPI_NONE, split_k=S)
+    acc = q(a, mode) @ q(w, mode).t()
+    close(slabs.sum(0), acc, mode, "split-K slab sum", tol=TOL["f32"] if mode == "f32" else 1e-4)
+    dx = torch.empty(M, N, device=dev())
+    o.layernorm_bwd(slabs, x.to(dev()), gam.to(dev()), dres.to(dev()), dx, None)
+    ref = dres.double() + R.ln_bwd(acc, x.double(), gam.double())
+    close(dx, ref, "f32", "ln bwd over split-K slabs", tol=2e-5 if mode == "f32" else 2e-4)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("patch,size", [(16, 64), (14, 56)])
 def test_patch_embed_matches_conv(mode, patch, size):
     from rpo_amd import _lib as L
