@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("group", c_i32),
         ("split_k", c_i32),
         ("split_stride", c_i64),
+        ("tile_config", c_i32),
     ]
 
 

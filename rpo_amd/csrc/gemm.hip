@@ -44,12 +44,10 @@ struct GemmParams {
   float* aux; int64_t ldaux; int aux_row0;
   int skip_row0, skip_col0, group;
   int split_k; int64_t split_stride;   // elements of C between slabs
+  int force_cfg;                       // 0 = heuristic; 1 small, 2 mid, 3 big (benchmarking)
 };
 
-constexpr int BM = 128, BN = 128;
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
-constexpr int TILE_BYTES = 128 * LROW;     // one operand tile (16 KiB)
-constexpr int SMEM_BYTES = 4 * TILE_BYTES; // 2 buffers x (A, W)
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> {
@@ -75,14 +73,43 @@ template <> struct Tr<float> {
   }
 };
 
-template <typename TIn, typename TOut, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
+// Tile configurations.  BM = WAVES_M * WM_T * 32 rows of A, BN = WAVES_N * WN_T * 32 rows of W,
+// NSTAGE LDS buffers of one k-tile each (BM + BN rows x 128 B).
+//   CfgSmall 128x128, 4 waves, 4 stages (128 KiB, 1 WG/CU): small-M GEMMs of the backward / text tower are
+//            a serial chain of k-tiles on few CUs, i.e. bound by the ~1 us DMA latency; three tiles in flight
+//   CfgMid   128x128, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): N = 768 GEMMs of the image forward (336 tiles)
+//   CfgBig   256x256, 8 waves, 2 stages (128 KiB, 1 WG/CU): in-proj / c_fc of the image forward.  A 128x128
+//            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU from L2, which IS the L2->CU rate, so it
+//            cannot pass ~50 % MFMA; 256x256 halves the bytes per flop.
+template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_>
+struct Cfg {
+  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, NSTAGE = NSTAGE_;
+  static constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
+  static constexpr int BM = WAVES_M * WM_T * 32, BN = WAVES_N * WN_T * 32;
+  static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int SMEM = NSTAGE * STAGE_BYTES;
+  static constexpr int DA = BM / 8 / NWAVES, DW = BN / 8 / NWAVES;   // DMA instructions per wave per k-tile
+  static constexpr int DPT = DA + DW;
+  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split over the waves");
+};
+using CfgSmall = Cfg<2, 2, 2, 2, 4>;
+using CfgMid = Cfg<2, 2, 2, 2, 2>;
+using CfgBig = Cfg<2, 4, 4, 2, 2>;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename TIn, typename TOut, int EPI, typename CF>
+__global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using T = Tr<TIn>;
+  constexpr int BM = CF::BM, BN = CF::BN, NSTAGE = CF::NSTAGE;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / CF::WAVES_N, wn = wave % CF::WAVES_N;
 
   const int tiles_n = (p.N + BN - 1) / BN;
   // XCD-aware bijective remap (guide T1): XCD x = bid % 8 gets a contiguous run of tiles
@@ -92,7 +119,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }
-  const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+  // grouped order: consecutive ids sweep GM m-tiles of one n-tile, then the next n-tile, so the
+  // workgroups resident on one XCD form a compact super-tile whose A and W panels fit its 4 MiB L2
+  constexpr int GM = 8;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group;
+  const int gm = min(GM, tiles_m - grp * GM);
+  const int in_grp = wg - grp * per_group;
+  const int tile_m = grp * GM + in_grp % gm, tile_n = in_grp / gm;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (p.skip_row0 >= 0 && m0 >= p.skip_row0 && n0 >= p.skip_col0) return;
 
@@ -103,74 +138,83 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   const int nk = kt1 - kt0;
   constexpr int KT_BYTES = T::BK * sizeof(TIn);  // 128
 
-  // DMA assignment: one operand tile = 16 wave-instructions of 1 KiB (8 rows); wave w issues
-  // instructions i*4 + w, i = 0..3.  Lane l -> row 8*(i*4+w) + (l>>3), physical chunk l&7, which
-  // must receive logical chunk (l&7) ^ ((row>>1)&7) of that row.
-  const char* ga[4];
-  const char* gw[4];
+  // DMA assignment: an operand tile of R rows = R/8 wave-instructions of 1 KiB (8 rows each); wave w issues
+  // instructions i*NWAVES + w.  Lane l -> row 8*(i*NWAVES+w) + (l>>3), physical chunk l&7, which must
+  // receive logical chunk (l&7) ^ ((row>>1)&7) of that row.
+  const char* ga[CF::DA];
+  const char* gw[CF::DW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * (i * 4 + wave) + (lane >> 3);
+  for (int i = 0; i < CF::DA; ++i) {
+    const int row = 8 * (i * CF::NWAVES + wave) + (lane >> 3);
     const int cl = (lane & 7) ^ ((row >> 1) & 7);
-    const int ra = min(m0 + row, p.M - 1);
-    const int rw = min(n0 + row, p.N - 1);
-    ga[i] = p.A + ((int64_t)ra * p.lda) * sizeof(TIn) + cl * 16 + (int64_t)kt0 * KT_BYTES;
-    gw[i] = p.W + ((int64_t)rw * p.ldw) * sizeof(TIn) + cl * 16 + (int64_t)kt0 * KT_BYTES;
+    ga[i] = p.A + ((int64_t)min(m0 + row, p.M - 1) * p.lda) * sizeof(TIn) + cl * 16 + (int64_t)kt0 * KT_BYTES;
+  }
+#pragma unroll
+  for (int i = 0; i < CF::DW; ++i) {
+    const int row = 8 * (i * CF::NWAVES + wave) + (lane >> 3);
+    const int cl = (lane & 7) ^ ((row >> 1) & 7);
+    gw[i] = p.W + ((int64_t)min(n0 + row, p.N - 1) * p.ldw) * sizeof(TIn) + cl * 16 + (int64_t)kt0 * KT_BYTES;
   }
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-#define RPO_DMA(BUF, KT)                                                                          \
-  do {                                                                                            \
-    char* b_ = smem + (BUF) * 2 * TILE_BYTES + wave * 1024;                                       \
-    const int64_t ko = (int64_t)(KT) * KT_BYTES;                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + ko), (lptr_t)(b_ + i * 4096), 16, 0, 0);  \
-      __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + ko), (lptr_t)(b_ + TILE_BYTES + i * 4096), 16, 0, 0); \
-    }                                                                                             \
-  } while (0)
+  auto dma = [&](int stage, int kt) {
+    char* b_ = smem + stage * CF::STAGE_BYTES + wave * 1024;
+    const int64_t ko = (int64_t)kt * KT_BYTES;
+#pragma unroll
+    for (int i = 0; i < CF::DA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + ko), (lptr_t)(b_ + i * CF::NWAVES * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < CF::DW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + ko), (lptr_t)(b_ + CF::A_BYTES + i * CF::NWAVES * 1024), 16,
+                                       0, 0);
+  };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[CF::WN_T][CF::WM_T];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < CF::WN_T; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CF::WM_T; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  // fragment rows of this lane: rows wm*64 + tm*32 + l31 (A side), wn*64 + tn*32 + l31 (W side);
-  // +32 rows keeps (row >> 1) & 7 unchanged, so one swizzle term per operand
-  const int rx = wm * 64 + l31, rwv = wn * 64 + l31;
+  // fragment rows of this lane (+32 rows per extra MFMA tile keeps (row >> 1) & 7 unchanged)
+  const int rx = wm * (CF::WM_T * 32) + l31, rwv = wn * (CF::WN_T * 32) + l31;
   const int swx = (rx >> 1) & 7, sww = (rwv >> 1) & 7;
 
-  RPO_DMA(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) dma(s, s);
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) RPO_DMA(cur ^ 1, kt + 1);
-    const char* sx = smem + cur * 2 * TILE_BYTES + rx * LROW;
-    const char* sw = smem + cur * 2 * TILE_BYTES + TILE_BYTES + rwv * LROW;
+    // tiles already issued: up to kt + NSTAGE - 2; tile kt must have landed
+    const int ahead = min(kt + NSTAGE - 2, nk - 1) - kt;
+    if (NSTAGE == 2 || ahead <= 0) wait_vmcnt<0>();
+    else if (ahead == 1) wait_vmcnt<CF::DPT>();
+    else if (NSTAGE > 3 && ahead == 2) wait_vmcnt<2 * CF::DPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everybody is done with tile kt-1
+    if (kt + NSTAGE - 1 < nk) dma((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+    const char* st = smem + (kt % NSTAGE) * CF::STAGE_BYTES;
+    const char* sx = st + rx * LROW;
+    const char* sw = st + CF::A_BYTES + rwv * LROW;
 #pragma unroll
     for (int ks = 0; ks < T::KSTEPS; ++ks) {
-      typename T::frag_t x0 = T::ldfrag(sx, swx, ks, half);
-      typename T::frag_t x1 = T::ldfrag(sx + 32 * LROW, swx, ks, half);
-      typename T::frag_t w0 = T::ldfrag(sw, sww, ks, half);
-      typename T::frag_t w1 = T::ldfrag(sw + 32 * LROW, sww, ks, half);
-      acc[0][0] = T::mfma(w0, x0, acc[0][0]);
-      acc[0][1] = T::mfma(w0, x1, acc[0][1]);
-      acc[1][0] = T::mfma(w1, x0, acc[1][0]);
-      acc[1][1] = T::mfma(w1, x1, acc[1][1]);
+      typename T::frag_t xf[CF::WM_T], wf[CF::WN_T];
+#pragma unroll
+      for (int tm = 0; tm < CF::WM_T; ++tm) xf[tm] = T::ldfrag(sx + tm * 32 * LROW, swx, ks, half);
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn) wf[tn] = T::ldfrag(sw + tn * 32 * LROW, sww, ks, half);
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < CF::WM_T; ++tm) acc[tn][tm] = T::mfma(wf[tn], xf[tm], acc[tn][tm]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (this wave's DMA)
-    __syncthreads();                                   // ... and everybody else's; buffer `cur` is free
   }
-#undef RPO_DMA
 
   // epilogue: acc[tn][tm] holds D[n][m]; lane: m = l31, n = 8*g + 4*half + j (reg = 4*g + j)
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = m0 + wm * 64 + tm * 32 + l31;
+  for (int tm = 0; tm < CF::WM_T; ++tm) {
+    const int m = m0 + wm * (CF::WM_T * 32) + tm * 32 + l31;
     if (m >= p.M) continue;
     int64_t orow = m;
     int prow = 0;
@@ -180,10 +224,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
       orow = (int64_t)m + img + 1;
     }
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < CF::WN_T; ++tn) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + tn * 32 + 8 * g + 4 * half;
+        const int n = n0 + wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -213,25 +257,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
           v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
         }
         ActIO<TOut>::st4(reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride + orow * p.ldc + n, v[0],
-                          v[1], v[2], v[3]);
+                         v[1], v[2], v[3]);
       }
     }
   }
 }
 
-template <typename TIn, typename TOut, int EPI>
-int launch(const GemmParams& p, hipStream_t s) {
+template <typename TIn, typename TOut, int EPI, typename CF>
+int launch_cfg(const GemmParams& p, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<TIn, TOut, EPI>;
+  auto kern = gemm_nt_kernel<TIn, TOut, EPI, CF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, p.split_k), dim3(256), SMEM_BYTES, s, p);
+  const int tiles = ((p.M + CF::BM - 1) / CF::BM) * ((p.N + CF::BN - 1) / CF::BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, p.split_k), dim3(CF::THREADS), CF::SMEM, s, p);
   return rpo_launch_status();
+}
+
+// shape heuristic (measured on MI355X, tools/bench_gemm.py): see the Cfg comments
+template <typename TIn, typename TOut, int EPI>
+int launch(const GemmParams& p, hipStream_t s) {
+  constexpr bool big_ok = sizeof(TIn) == 2 && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU);
+  if (p.force_cfg == 1) return launch_cfg<TIn, TOut, EPI, CfgSmall>(p, s);
+  if (p.force_cfg == 2) return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
+  if constexpr (big_ok) {
+    if (p.force_cfg == 3 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && p.split_k == 1))
+      return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
+  }
+  if (p.M >= 2048) return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
+  return launch_cfg<TIn, TOut, EPI, CfgSmall>(p, s);
 }
 
 template <typename TIn, typename TOut>
@@ -288,6 +346,7 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.skip_row0 = a->skip_row0; p.skip_col0 = a->skip_col0; p.group = a->group;
   p.split_k = a->split_k <= 1 ? 1 : a->split_k;
   p.split_stride = a->split_stride;
+  p.force_cfg = a->tile_config;
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -356,6 +356,12 @@ class Engine:
         self._image_backward(B)
         main.wait_stream(self.side)
 
+    def head(self, B: int, label: torch.Tensor) -> None:
+        K, e, n = self.cfg.K, self.cfg.embed, self.cfg.n_cls
+        ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(n, K, e), label, self.logit_scale_exp,
+                         self.logits[:B], self.loss, self.d_img_f[:B * K].view(B, K, e),
+                         self.d_text_f.view(n, K, e), self.head_ws)
+
     def _check(self, image: torch.Tensor) -> int:
         cfg = self.cfg
         assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous()

@@ -46,7 +46,7 @@ def version() -> int:
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
             aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
-            group: int = 0, m_rows: Optional[int] = None, split_k: int = 1) -> torch.Tensor:
+            group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer."""
@@ -64,7 +64,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     epilogue=epilogue, bias=_p(bias), resid=_p(resid), ldr=0 if resid is None else _ld(resid),
                     aux=_p(aux), ldaux=0 if aux is None else _ld(aux), aux_row0=aux_row0,
                     skip_row0=skip_row0, skip_col0=skip_col0, group=group, split_k=split_k,
-                    split_stride=split_stride)
+                    split_stride=split_stride, tile_config=tile_config)
     check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
     return out
 

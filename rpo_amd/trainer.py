@@ -63,7 +63,7 @@ class RPO:
         self.epoch = 0
         self.batch_idx = 0
         self._steps = 0
-        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph = None
         self.build_model(state_dict, tokens, act_dtype, prompts)
 
     # trainers/rpo.py:240-288
@@ -84,13 +84,48 @@ class RPO:
                 batch["label"].to(self.device, dtype=torch.int64, non_blocking=True))
 
     def _capture(self) -> None:
-        eng = self.engine
+        """Capture the step as FIVE HIP graphs on two streams instead of one graph with parallel
+        branches: ROCm's graph executor started the image branch only after ~1.2 ms of the (latency-
+        bound, tiny) text branch (rocprof timeline, profiles/), so the fork/join is done with stream
+        events between graph launches -- text fwd | image fwd  ->  head  ->  text bwd | image bwd."""
+        eng, B = self.engine, self.batch_size
         eng.forward_backward(self._image, self._label)          # eager warm-up: sets kernel attributes,
         torch.cuda.synchronize()                                # builds the text K/V cache
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            eng.forward_backward(self._image, self._label)
-        self._graph = g
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):               # a graph replays on whatever stream is current at replay()
+                fn()
+            return g
+
+        self._g_text_fwd = cap(lambda: eng._text_forward(train=True))
+        self._g_img_fwd = cap(lambda: eng._image_forward(self._image, train=True))
+        self._g_head = cap(lambda: eng.head(B, self._label))
+        self._g_text_bwd = cap(eng._text_backward)
+        self._g_img_bwd = cap(lambda: eng._image_backward(B))
+        self._ev_fork = torch.cuda.Event()
+        self._ev_text_fwd = torch.cuda.Event()
+        self._ev_head = torch.cuda.Event()
+        self._ev_text_bwd = torch.cuda.Event()
+        self._graph = True
+        torch.cuda.synchronize()
+
+    def _replay(self) -> None:
+        main, side = torch.cuda.current_stream(), self.engine.side
+        self._ev_fork.record(main)                  # inputs / updated prompts are ready
+        side.wait_event(self._ev_fork)
+        with torch.cuda.stream(side):
+            self._g_text_fwd.replay()
+            self._ev_text_fwd.record(side)
+        self._g_img_fwd.replay()
+        main.wait_event(self._ev_text_fwd)
+        self._g_head.replay()
+        self._ev_head.record(main)
+        side.wait_event(self._ev_head)
+        with torch.cuda.stream(side):
+            self._g_text_bwd.replay()
+            self._ev_text_bwd.record(side)
+        self._g_img_bwd.replay()
+        main.wait_event(self._ev_text_bwd)
 
     def forward_backward(self, batch) -> Dict[str, float]:
         """trainers/rpo.py:290-316."""
@@ -113,7 +148,7 @@ class RPO:
         if self.use_graph:
             if self._graph is None:
                 self._capture()
-            self._graph.replay()
+            self._replay()
         else:
             eng.forward_backward(self._image, self._label)
         self.sync.all_reduce_sum(eng.grads)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of rpo_gemm_nt at the shapes of the B=32 ViT-B/16 step (HIP events)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rpo_amd import ops
+from rpo_amd._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_QGELU_BWD
+
+dev = torch.device("cuda:0")
+SHAPES = [  # name, M, N, K, epi, out dtype, split
+    ("qkv", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 1),
+    ("out_proj", 7072, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
+    ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("c_proj", 7072, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
+    ("bwd_du", 768, 3072, 768, EPI_QGELU_BWD, torch.bfloat16, 1),
+    ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 8),
+    ("bwd_da", 768, 768, 768, EPI_NONE, torch.bfloat16, 1),
+    ("bwd_dh1", 768, 768, 768, EPI_NONE, torch.float32, 4),
+    ("txt_q", 456, 512, 512, EPI_BIAS, torch.bfloat16, 1),
+    ("txt_fc", 456, 2048, 512, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("txt_proj", 456, 512, 2048, EPI_BIAS_RESID, torch.float32, 1),
+]
+for name, M, N, K, epi, odt, split in SHAPES:
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    out = torch.empty((split, M, N) if split > 1 else (M, N), dtype=odt, device=dev)
+    bias = torch.randn(N, device=dev)
+    resid = torch.randn(M, N, device=dev)
+    aux = torch.randn(M, N, device=dev)
+    kw = dict(bias=bias if epi in (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID) else None,
+              resid=resid if epi == EPI_BIAS_RESID else None,
+              aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
+    res = []
+    cfgs = [1, 2] + ([3] if epi in (EPI_BIAS, EPI_BIAS_QGELU) else [])
+    for cfg in [0] + cfgs:
+        for _ in range(3):
+            ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)
+        g.replay()
+        s.record(); g.replay(); e.record(); e.synchronize()
+        us = 1e3 * s.elapsed_time(e) / 20
+        res.append(f"cfg{cfg}: {us:7.2f} us {2.0*M*N*K/us/1e6:7.1f} TF")
+    print(f"{name:9s} M={M:5d} N={N:5d} K={K:5d} split={split}: " + " | ".join(res))
