@@ -82,8 +82,8 @@ typedef struct rpo_gemm_args {
                                     slice s writes its partial product to C + s * split_stride; the
                                     consumer (rpo_layernorm_bwd's dy_splits) adds the slabs in order    */
   int64_t split_stride;          /* elements between slabs (>= M * ldc)                            */
-  int32_t tile_config;           /* 0 = choose by shape; 1 = 128x128x4-stage, 2 = 128x128x2-stage,
-                                    3 = 256x256 (bf16 BIAS / BIAS_QGELU only): for benchmarking       */
+  int32_t tile_config;           /* 0 = choose by shape; 2 = 128x128 tiles, 3 = 256x256 tiles (bf16 in/out,
+                                    EPI_BIAS only; falls back to 128x128 otherwise): for benchmarking */
 } rpo_gemm_args;
 
 int rpo_version(void);

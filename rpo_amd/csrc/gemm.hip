@@ -75,12 +75,11 @@ template <> struct Tr<float> {
 
 // Tile configurations.  BM = WAVES_M * WM_T * 32 rows of A, BN = WAVES_N * WN_T * 32 rows of W,
 // NSTAGE LDS buffers of one k-tile each (BM + BN rows x 128 B).
-//   CfgSmall 128x128, 4 waves, 4 stages (128 KiB, 1 WG/CU): small-M GEMMs of the backward / text tower are
-//            a serial chain of k-tiles on few CUs, i.e. bound by the ~1 us DMA latency; three tiles in flight
-//   CfgMid   128x128, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): N = 768 GEMMs of the image forward (336 tiles)
-//   CfgBig   256x256, 8 waves, 2 stages (128 KiB, 1 WG/CU): in-proj / c_fc of the image forward.  A 128x128
-//            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU from L2, which IS the L2->CU rate, so it
+//   CfgMid   128x128, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): the default
+//   CfgBig   256x256, 8 waves, 2 stages (128 KiB, 1 WG/CU): in-proj of the image forward.  A 128x128
+//            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU, which IS the L1/L2->CU rate, so it
 //            cannot pass ~50 % MFMA; 256x256 halves the bytes per flop.
+// (NSTAGE > 2 is supported by the counted-vmcnt loop below; a 4-stage 128x128 variant measured slower.)
 template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_>
 struct Cfg {
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, NSTAGE = NSTAGE_;
@@ -92,7 +91,6 @@ struct Cfg {
   static constexpr int DPT = DA + DW;
   static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split over the waves");
 };
-using CfgSmall = Cfg<2, 2, 2, 2, 4>;
 using CfgMid = Cfg<2, 2, 2, 2, 2>;
 using CfgBig = Cfg<2, 4, 4, 2, 2>;
 
@@ -281,15 +279,15 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
 // shape heuristic (measured on MI355X, tools/bench_gemm.py): see the Cfg comments
 template <typename TIn, typename TOut, int EPI>
 int launch(const GemmParams& p, hipStream_t s) {
-  constexpr bool big_ok = sizeof(TIn) == 2 && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU);
-  if (p.force_cfg == 1) return launch_cfg<TIn, TOut, EPI, CfgSmall>(p, s);
-  if (p.force_cfg == 2) return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
+  // measured (tools/bench_gemm.py, profiles/): 256x256 wins only for the in-proj (37.7 vs 42.1 us); with the
+  // QuickGELU epilogue the store burst of a single-round 256x256 launch loses to 128x128 (69 vs 62 us); the
+  // 4-stage 128x128 variant was slower than the 2-stage one on every shape and is not instantiated
+  constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 && EPI == RPO_EPI_BIAS;
   if constexpr (big_ok) {
     if (p.force_cfg == 3 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && p.split_k == 1))
       return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
   }
-  if (p.M >= 2048) return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
-  return launch_cfg<TIn, TOut, EPI, CfgSmall>(p, s);
+  return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
 }
 
 template <typename TIn, typename TOut>
