@@ -44,8 +44,23 @@ struct GemmParams {
   float* aux; int64_t ldaux; int aux_row0;
   int skip_row0, skip_col0, group;
   int split_k; int64_t split_stride;   // elements of C between slabs
-  int force_cfg;                       // 0 = heuristic; 1 small, 2 mid, 3 big (benchmarking)
+  int force_cfg;                       // 0 = heuristic; 2 = 128x128, 3 = 256x256 (benchmarking)
 };
+
+// Optional in-kernel timeline (build with -DRPO_GEMM_TIMELINE; tools/gemm_timeline.py): wave 0 of a few
+// workgroups stamps s_memtime at the phase boundaries into a global buffer set by rpo_debug_set_timeline.
+#ifdef RPO_GEMM_TIMELINE
+}  // namespace
+__device__ unsigned long long* g_timeline = nullptr;
+namespace {
+#define RPO_STAMP(slot)                                                                        \
+  do {                                                                                         \
+    if (g_timeline != nullptr && tid == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)    \
+      g_timeline[(blockIdx.x / 97) * 64 + (slot)] = __builtin_amdgcn_s_memtime();              \
+  } while (0)
+#else
+#define RPO_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
 
@@ -75,7 +90,9 @@ template <> struct Tr<float> {
 
 // Tile configurations.  BM = WAVES_M * WM_T * 32 rows of A, BN = WAVES_N * WN_T * 32 rows of W,
 // NSTAGE LDS buffers of one k-tile each (BM + BN rows x 128 B).
-//   CfgMid   128x128, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): the default
+//   CfgMid   128x128, 8 waves (64x32 each), 2 stages (66 KiB, 2 WG/CU): the default.  Issuing one
+//            1-KiB LDS-DMA costs a wave ~100 issue cycles, in order with its MFMAs; 8 waves halve the DMA
+//            and MFMA share of each and let the 4 waves per SIMD overlap them (2-20 % over 4 waves)
 //   CfgBig   256x256, 8 waves, 2 stages (128 KiB, 1 WG/CU): in-proj of the image forward.  A 128x128
 //            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU, which IS the L1/L2->CU rate, so it
 //            cannot pass ~50 % MFMA; 256x256 halves the bytes per flop.
@@ -86,12 +103,16 @@ struct Cfg {
   static constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
   static constexpr int BM = WAVES_M * WM_T * 32, BN = WAVES_N * WN_T * 32;
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int SMEM = NSTAGE * STAGE_BYTES;
+  // epilogue staging (see the kernel): 256x256 stages the bf16 result, everything else the fp32 accumulators
+  static constexpr bool PRECONV_EPI = BM * (BN * 4 + 16) > 140 * 1024;
+  static constexpr int CROW_BYTES(bool preconv) { return preconv ? BN * 2 + 16 : BN * 4 + 16; }
+  static constexpr int EPI_BYTES = BM * CROW_BYTES(PRECONV_EPI);
+  static constexpr int SMEM = NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES;
   static constexpr int DA = BM / 8 / NWAVES, DW = BN / 8 / NWAVES;   // DMA instructions per wave per k-tile
   static constexpr int DPT = DA + DW;
   static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split over the waves");
 };
-using CfgMid = Cfg<2, 2, 2, 2, 2>;
+using CfgMid = Cfg<2, 4, 2, 1, 2>;
 using CfgBig = Cfg<2, 4, 4, 2, 2>;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -109,6 +130,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave / CF::WAVES_N, wn = wave % CF::WAVES_N;
 
+  RPO_STAMP(0);
   const int tiles_n = (p.N + BN - 1) / BN;
   // XCD-aware bijective remap (guide T1): XCD x = bid % 8 gets a contiguous run of tiles
   int wg;
@@ -191,6 +213,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     else if (NSTAGE > 3 && ahead == 2) wait_vmcnt<2 * CF::DPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everybody is done with tile kt-1
+    RPO_STAMP(2 + min(kt, 50));
     if (kt + NSTAGE - 1 < nk) dma((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
     const char* st = smem + (kt % NSTAGE) * CF::STAGE_BYTES;
     const char* sx = st + rx * LROW;
@@ -209,56 +232,130 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     }
   }
 
-  // epilogue: acc[tn][tm] holds D[n][m]; lane: m = l31, n = 8*g + 4*half + j (reg = 4*g + j)
+  RPO_STAMP(60);
+  // ---- epilogue, staged through LDS -------------------------------------------------------------
+  // acc[tn][tm] holds D[n][m] (lane: m = l31, n = 8*g + 4*half + j, reg = 4*g + j).  Storing straight from
+  // that layout means 8-B pieces scattered over 32 rows per instruction; measured with s_memtime it cost
+  // 9-24 k cycles per workgroup (25-33 % of its lifetime; the store tail is issue-bound, guide T21).  So the
+  // tile is first written to LDS (free after the last k-tile), then walked row-major: every global load
+  // (residual, saved pre-activation) and store is a fully coalesced 16-B-per-lane access.
+  //   PRECONV (256x256, bf16 out, bias only): bias added in the fragment layout, tile staged as bf16
+  //   otherwise: tile staged as fp32, bias / residual / QuickGELU applied in the row-major pass
+  constexpr bool PRECONV = CF::PRECONV_EPI;
+  constexpr int CROW = CF::CROW_BYTES(PRECONV);
+  constexpr bool HAS_BIAS = EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID;
+  __builtin_amdgcn_s_barrier();              // everybody is done reading the last stage
+  if constexpr (PRECONV) {
+    const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
+    float4 bias_r[CF::WN_T][4];
 #pragma unroll
-  for (int tm = 0; tm < CF::WM_T; ++tm) {
-    const int m = m0 + wm * (CF::WM_T * 32) + tm * 32 + l31;
-    if (m >= p.M) continue;
-    int64_t orow = m;
-    int prow = 0;
-    if (EPI == RPO_EPI_PATCH) {
-      const int img = m / p.group;
-      prow = m - img * p.group + 1;
-      orow = (int64_t)m + img + 1;
+    for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias_r[tn][g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tm = 0; tm < CF::WM_T; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
+          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
+          const float4 b4 = bias_r[tn][g];
+          float4 v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
+                                 acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
+          if (EPI == RPO_EPI_BIAS_QGELU) {
+            const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
+            if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
+              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+          }
+          *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
+              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                       // 16-B chunks per row
+    constexpr int RPP = CF::THREADS / CPR;            // rows per pass
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+#pragma unroll 4
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      const int row = pass * RPP + r0;
+      const int m = m0 + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
     }
+  } else {
 #pragma unroll
-    for (int tn = 0; tn < CF::WN_T; ++tn) {
+    for (int tm = 0; tm < CF::WM_T; ++tm)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
-        if (n >= p.N) continue;
-        float v[4];
+      for (int tn = 0; tn < CF::WN_T; ++tn)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * g + j];
-        if (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID) {
-          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        for (int g = 0; g < 4; ++g) {
+          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
+          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
+          *reinterpret_cast<float4*>(smem + row * CROW + col * 4) =
+              make_float4(acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]);
         }
+    __syncthreads();
+    constexpr int CPR = BN / 4;                       // float4 chunks per row
+    constexpr int RPP = CF::THREADS / CPR;
+    constexpr int UNR = 4;                            // rows whose loads are issued together
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 4;
+    const bool nok = n < p.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
+    for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
+      float4 ex[UNR];
+      int64_t orow[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int m = m0 + (pass0 + u) * RPP + r0;
+        ok[u] = nok && m < p.M;
+        const int mc = min(m, p.M - 1);
+        orow[u] = mc;
+        ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == RPO_EPI_PATCH) {
+          const int img = mc / p.group;
+          orow[u] = (int64_t)mc + img + 1;
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
+        } else if (EPI == RPO_EPI_BIAS_RESID) {
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
+        } else if (EPI == RPO_EPI_QGELU_BWD) {
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int row = (pass0 + u) * RPP + r0;
+        const int m = m0 + row;
+        float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
         if (EPI == RPO_EPI_BIAS_QGELU) {
-          if (p.aux != nullptr && m >= p.aux_row0)
-            *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) =
-                make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+          if (ok[u] && p.aux != nullptr && m >= p.aux_row0)
+            *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+          v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
         }
-        if (EPI == RPO_EPI_BIAS_RESID) {
-          const float4 r4 = *reinterpret_cast<const float4*>(p.resid + (int64_t)m * p.ldr + n);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
+          v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
         }
         if (EPI == RPO_EPI_QGELU_BWD) {
-          const float4 u4 = *reinterpret_cast<const float4*>(p.aux + (int64_t)m * p.ldaux + n);
-          v[0] *= quick_gelu_grad(u4.x); v[1] *= quick_gelu_grad(u4.y);
-          v[2] *= quick_gelu_grad(u4.z); v[3] *= quick_gelu_grad(u4.w);
+          v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
+          v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
         }
-        if (EPI == RPO_EPI_PATCH) {
-          const float4 r4 = *reinterpret_cast<const float4*>(p.resid + (int64_t)prow * p.ldr + n);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
-        ActIO<TOut>::st4(reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride + orow * p.ldc + n, v[0],
-                         v[1], v[2], v[3]);
+        if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
       }
     }
   }
+#ifdef RPO_GEMM_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(61);
 }
 
 template <typename TIn, typename TOut, int EPI, typename CF>
@@ -279,12 +376,17 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
 // shape heuristic (measured on MI355X, tools/bench_gemm.py): see the Cfg comments
 template <typename TIn, typename TOut, int EPI>
 int launch(const GemmParams& p, hipStream_t s) {
-  // measured (tools/bench_gemm.py, profiles/): 256x256 wins only for the in-proj (37.7 vs 42.1 us); with the
-  // QuickGELU epilogue the store burst of a single-round 256x256 launch loses to 128x128 (69 vs 62 us); the
-  // 4-stage 128x128 variant was slower than the 2-stage one on every shape and is not instantiated
-  constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 && EPI == RPO_EPI_BIAS;
+  // measured (tools/bench_gemm.py, profiles/): 256x256 wins for the wide-N forward GEMMs of the image tower
+  // (in-proj 31.6 vs 36.1 us); a 4-stage 128x128 variant was slower than 2 stages on every shape
+  constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU);
   if constexpr (big_ok) {
-    if (p.force_cfg == 3 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && p.split_k == 1))
+    // one 256x256 workgroup per CU: only worth it when the tiles fill whole rounds of the 256 CUs
+    // (in-proj at B=32: 252 tiles; c_fc: 336 tiles = 1.3 rounds -> 65 us vs 55 us with 128x128)
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int rounds = (tiles + 255) / 256;
+    const bool fills = tiles * 100 >= rounds * 256 * 85;
+    if (p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C) &&
+        (p.force_cfg == 3 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills)))
       return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
   }
   return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
@@ -311,6 +413,12 @@ int dispatch_f32out(int epi, const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef RPO_GEMM_TIMELINE
+extern "C" int rpo_debug_set_timeline(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return RPO_E_BADARG;

@@ -31,7 +31,7 @@ for name, M, N, K, epi, odt, split in SHAPES:
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
     res = []
-    cfgs = [2] + ([3] if epi == EPI_BIAS else [])
+    cfgs = [2] + ([3] if epi in (EPI_BIAS, EPI_BIAS_QGELU) else [])
     for cfg in [0] + cfgs:
         for _ in range(3):
             ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)
