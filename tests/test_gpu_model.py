@@ -185,3 +185,32 @@ def test_checkpoint_roundtrip(tmp_path):
     a = tr.model_inference(torch.from_numpy(image).cuda())
     b = tr2.model_inference(torch.from_numpy(image).cuda())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("act,tol", [(torch.float32, TOL_F32), (torch.bfloat16, None)])
+def test_vit_l14_dims_against_oracle(act, tol):
+    """BASELINE.json configs[3]: ViT-L/14 (d=1024, 16 heads, patch 14 -> 257 frozen tokens, text width 768,
+    embed 768).  The reference cannot run it (SURVEY.md finding 7); the dimension-generic oracle pins it.
+    Depth is reduced to keep the CPU oracle fast; every width / head count / tile path is the real one."""
+    from oracle.rpo_oracle import OracleRPO
+    from rpo_amd.config import vit_l14
+    from rpo_amd.custom_clip import CustomCLIP
+    cfg = vit_l14(layers_v=2, layers_t=2, K=24)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=5, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=9)
+    image, label = synth.images(cfg, 2), synth.labels(cfg, 2)
+    o = OracleRPO(sd, toks, cfg.K, cfg.patch)
+    o.set_prompts(tp, ip)
+    out, gt, gi = o.loss_and_grads(image, label)
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=2, prompts=(tp, ip))
+    loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    loss.backward()
+    el = abs(loss.item() - out.loss.item())
+    rt = _relmax(m.prompt_learner.text_prompt.grad.cpu().numpy(), gt.numpy())
+    ri = _relmax(m.prompt_learner.img_prompt.grad.cpu().numpy(), gi.numpy())
+    print(f"[ViT-L/14 {act}] loss err {el:.2e} g_text rel {rt:.2e} g_img rel {ri:.2e}")
+    if tol is not None:
+        assert el <= tol and rt <= tol and ri <= tol
+    else:
+        assert el <= 0.1 and rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL

@@ -45,3 +45,25 @@ for order in ("text-first", "img-first"):
         with torch.cuda.stream(side): tr._g_text_bwd.replay()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"bwd {order}: host {1e6*(t1-t0):8.1f} us total {1e6*(t2-t0):8.1f} us")
+
+# --- emulate the cross-step pipeline: frozen forward of batch i+1 (stream A) concurrently with the whole
+# small-kernel chain of batch i (text fwd + [text fwd again ~ prompt-row image fwd] + head + both backward chains)
+main = torch.cuda.current_stream()
+sb, sc = torch.cuda.Stream(), torch.cuda.Stream()
+ev1, ev2, ev3 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tr._g_img_fwd.replay()                               # A: F(i+1)
+    with torch.cuda.stream(sb):
+        tr._g_text_fwd.replay()
+        tr._g_text_fwd.replay()                          # stands in for the prompt-row image forward chain
+        tr._g_head.replay()
+        ev1.record(sb)
+    sc.wait_event(ev1)
+    with torch.cuda.stream(sc):
+        tr._g_img_bwd.replay(); ev2.record(sc)
+    with torch.cuda.stream(sb):
+        tr._g_text_bwd.replay(); ev3.record(sb)
+    main.wait_event(ev2); main.wait_event(ev3)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"pipeline emulation: {1e6*(t2-t0):8.1f} us per step")
