@@ -82,8 +82,8 @@ typedef struct rpo_gemm_args {
                                     slice s writes its partial product to C + s * split_stride; the
                                     consumer (rpo_layernorm_bwd's dy_splits) adds the slabs in order    */
   int64_t split_stride;          /* elements between slabs (>= M * ldc)                            */
-  int32_t tile_config;           /* 0 = choose by shape; 2 = 128x128 tiles, 3 = 256x256 tiles (bf16 in/out,
-                                    EPI_BIAS only; falls back to 128x128 otherwise): for benchmarking */
+  int32_t tile_config;           /* 0 = choose by shape; for benchmarking: 2 = 128x128 tiles, 3 = 256x256 (bf16
+                                    in/out, BIAS / BIAS_QGELU only, else falls through), 5 = 64x64, 6 = 64x128 */
 } rpo_gemm_args;
 
 int rpo_version(void);

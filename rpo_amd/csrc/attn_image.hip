@@ -17,8 +17,13 @@
 // from LDS in that same order (any k-permutation applied to both operands cancels), so no
 // lane movement is needed between softmax and P.V.
 //
-// bf16: v_mfma_f32_32x32x16_bf16; K rows padded to 144 B, V stored transposed [64][Npad+4]
-//       so an A-operand fragment (8 keys for one d) is two 8-B LDS reads.
+// bf16: v_mfma_f32_32x32x16_bf16; K rows padded to 144 B.  The P.V (and, in the backward, dS.K) MFMAs
+//       contract over KEYS, i.e. need the row-major [key][d] operand transposed.  It is transposed on the
+//       matrix core itself: D = M_tile . I (A = 32 rows of M exactly as they sit in memory, B = identity)
+//       lands in the C/D layout "lane = d, registers = keys", which after bf16 packing IS the A-operand
+//       fragment of M^T in this kernel's key order -- exact, no 2-byte LDS scatter, no bank conflicts.
+//       The forward does it once per key tile (one wave each) and parks the fragments in LDS
+//       fragment-major (lane-linear 16-B writes/reads); the backward keeps them in registers.
 // f32 : v_mfma_f32_32x32x2_f32 (exact f32 fma chain); one float per lane per operand, so
 //       K and V stay row-major [Npad][65].
 #include "common.h"
@@ -34,15 +39,20 @@ template <int NT> struct AL<bf16_t, NT> {
   static constexpr int TROW = (NPAD + 4) * 2;      // bytes per transposed row
   static constexpr int K_BYTES = NPAD * KROW;
   static constexpr int T_BYTES = 64 * TROW;
-  static constexpr int FWD_BYTES = K_BYTES + T_BYTES;           // Ks | Vt
-  static constexpr int BWD_BYTES = 2 * K_BYTES + T_BYTES;       // Ks | Vs | Kt
+  static constexpr int F_BYTES = NT * 4 * 1024;                  // V^T fragments: [NT][2 dt][2 g2][64 lanes][16 B]
+  static constexpr int PART_BYTES = 4 * 16 * 64 * 16 + 4 * 64 * 4;  // backward cross-wave partials
+  static constexpr int FWD_BYTES = K_BYTES + F_BYTES;            // Ks | Vfrag
+  static constexpr int BWD_STAGE = 2 * K_BYTES;                  // Ks | Vs
+  static constexpr int BWD_BYTES = BWD_STAGE > PART_BYTES ? BWD_STAGE : PART_BYTES;
 };
 template <int NT> struct AL<float, NT> {
   static constexpr int NPAD = NT * 32;
   static constexpr int ROWF = 65;                  // floats per row
   static constexpr int K_BYTES = NPAD * ROWF * 4;
+  static constexpr int PART_BYTES = 4 * 16 * 64 * 16 + 4 * 64 * 4;
   static constexpr int FWD_BYTES = 2 * K_BYTES;    // Ks | Vs
-  static constexpr int BWD_BYTES = 2 * K_BYTES;
+  static constexpr int BWD_STAGE = 2 * K_BYTES;
+  static constexpr int BWD_BYTES = BWD_STAGE > PART_BYTES ? BWD_STAGE : PART_BYTES;
 };
 
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
@@ -57,6 +67,34 @@ __device__ __forceinline__ bf16x8_t join8(uint2 lo, uint2 hi) {
   u32x4 u;
   u[0] = lo.x; u[1] = lo.y; u[2] = hi.x; u[3] = hi.y;
   return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// B-operand identity fragment for the k-step pair (ks2 = 0, 1) of a 32-wide d' tile: element jj of lane
+// (j = l31, half) is I[k][j] with k = 16*ks2 + 8*half + jj
+__device__ __forceinline__ bf16x8_t ident_frag(int ks2, int l31, int half) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 u;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int k0 = 16 * ks2 + 8 * half + 2 * w;
+    u[w] = (k0 == l31 ? 0x3F80u : 0u) | (k0 + 1 == l31 ? 0x3F800000u : 0u);
+  }
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+// rows[4] = the four 16-element A fragments (d = 0..63) of 32 rows of a row-major matrix M; returns the
+// A fragments of M^T for d' tile dt: out[g2] covers this kernel's key slots 8*g2 .. 8*g2+7
+__device__ __forceinline__ void transpose_tile(const bf16x8_t (&rows)[4], int dt, const bf16x8_t& i0,
+                                               const bf16x8_t& i1, bf16x8_t (&out)[2]) {
+  f32x16_t d;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[r] = 0.f;
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rows[2 * dt], i0, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rows[2 * dt + 1], i1, d, 0, 0, 0);
+  float f[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f[r] = d[r];
+  out[0] = pack8(f);
+  out[1] = pack8(f + 8);
 }
 
 // ---- staging ---------------------------------------------------------------------------
@@ -198,25 +236,23 @@ __device__ __forceinline__ void softmax_rows(f32x16_t (&acc)[NT], int N, int hal
     for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
 }
 
-// o[dt] += Mt-contraction:  D[d][q] += sum_key M[key][d] * w[q][key], keys of tile t.
-// bf16: M stored transposed (mt, [64][NPAD+4]); f32: M row-major (ms, [NPAD][65]).
+// o[dt] += M^T-contraction:  D[d][q] += sum_key M[key][d] * w[q][key], keys of tile t.
+// bf16: M^T fragments parked fragment-major in LDS (frag, [NT][2][2][64][16 B]); f32: M row-major (ms, [NPAD][65]).
 template <typename T, int NT>
 __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f32x16_t& w, f32x16_t (&o)[2],
                                               int l31, int half) {
   if constexpr (sizeof(T) == 2) {
-    constexpr int TROW = AL<bf16_t, NT>::TROW;
     float wf[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) wf[r] = w[r];
+    const int lane = l31 + 32 * half;
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
       const bf16x8_t b = pack8(wf + 8 * g2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const char* rowp = m_lds + (32 * dt + l31) * TROW + (32 * t + 16 * g2 + 4 * half) * 2;
-        const uint2 lo = *reinterpret_cast<const uint2*>(rowp);
-        const uint2 hi = *reinterpret_cast<const uint2*>(rowp + 16);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo, hi), b, o[dt], 0, 0, 0);
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(m_lds + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, o[dt], 0, 0, 0);
       }
     }
   } else {
@@ -247,7 +283,26 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
   char* vs = smem + L::K_BYTES;
   if constexpr (sizeof(T) == 2) {
     stage_bf16<NT, 512, true, false>(ks, nullptr, kb, ld, N, tid);
-    stage_bf16<NT, 512, false, true>(nullptr, vs, vb, ld, N, tid);
+    // V^T fragments: wave w transposes key tiles w, w+8 on the matrix core, rows straight from HBM
+    const bf16x8_t i0 = ident_frag(0, l31, half), i1 = ident_frag(1, l31, half);
+    for (int t = wave; t < NT; t += 8) {
+      const int key = 32 * t + l31;
+      bf16x8_t rows[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (key < N) z = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ld + kk * 16 + half * 8);
+        rows[kk] = __builtin_bit_cast(bf16x8_t, z);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x8_t fr[2];
+        transpose_tile(rows, dt, i0, i1, fr);
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+          *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
+      }
+    }
   } else {
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(ks), kb, ld, N, tid);
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(vs), vb, ld, N, tid);
@@ -290,6 +345,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
 // ---- backward (prompt rows only; dq) -----------------------------------------------------
 // dq = scale * (U - delta * W),  U = sum_key (p*dp)[key] K[key],  W = sum_key p[key] K[key],
 // delta = sum_key p*dp, dp = da . V^T.  One pass over the key tiles, no saved forward output.
+// The 4 waves of the workgroup share one 32-query tile: each recomputes the (cheap) score tile row
+// statistics, then takes the key tiles t = wave, wave+4, ... for dP / U / W; partial U, W, delta are
+// combined through LDS (the staging area is dead by then).
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
                                                        const T* __restrict__ k, const T* __restrict__ v,
@@ -298,25 +356,31 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
                                                        float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const T* kb = k + (int64_t)b * N * ldkv + h * 64;
   const T* vb = v + (int64_t)b * N * ldkv + h * 64;
   char* ks = smem;
   char* vs = smem + L::K_BYTES;
-  char* kt = smem + 2 * L::K_BYTES;  // bf16 only
-  if constexpr (sizeof(T) == 2) {
-    stage_bf16<NT, 256, true, true>(ks, kt, kb, ldkv, N, tid);   // one pass: K row-major + K^T
-    stage_bf16<NT, 256, true, false>(vs, nullptr, vb, ldkv, N, tid);
-  } else {
-    stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
-    stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
-    kt = ks;
-  }
-  __syncthreads();
+  float4* part_u = reinterpret_cast<float4*>(smem);                 // [4 waves][8 groups][64 lanes]
+  float4* part_w = part_u + 4 * 8 * 64;
+  float* part_d = reinterpret_cast<float*>(part_w + 4 * 8 * 64);    // [4 waves][64 lanes]
+  bf16x8_t i0, i1;
+  if constexpr (sizeof(T) == 2) { i0 = ident_frag(0, l31, half); i1 = ident_frag(1, l31, half); }
 
-  for (int qt = wave; qt * 32 < Kp; qt += 4) {
+  const int nqt = (Kp + 31) / 32;
+  for (int qt = 0; qt < nqt; ++qt) {
+    if (qt > 0) __syncthreads();                   // partials of the previous tile have been consumed
+    if constexpr (sizeof(T) == 2) {
+      stage_bf16<NT, 256, true, false>(ks, nullptr, kb, ldkv, N, tid);
+      stage_bf16<NT, 256, true, false>(vs, nullptr, vb, ldkv, N, tid);
+    } else {
+      stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
+      stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
+    }
+    __syncthreads();
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
     const int i = qt * 32 + l31;
@@ -335,42 +399,78 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
     float delta = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if ((t & 3) != wave) continue;               // wave-uniform
       f32x16_t dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
       if constexpr (sizeof(T) == 2) {
-        const char* rowp = vs + (32 * t + l31v) * 144 + half * 16;
+        const char* vrow = vs + (32 * t + l31v) * 144 + half * 16;
+        const char* krow = ks + (32 * t + l31v) * 144 + half * 16;
+        bf16x8_t krows[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + kk * 32);
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vrow + kk * 32);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df.f[kk], dp, 0, 0, 0);
+          krows[kk] = *reinterpret_cast<const bf16x8_t*>(krow + kk * 32);
+        }
+        float pw[16], pp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pp[r] = p[t][r];
+          pw[r] = dp[r] * pp[r];                   // p * dp  (p = 0 on padded keys)
+          delta += pw[r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t ktf[2];
+          transpose_tile(krows, dt, i0, i1, ktf);  // K^T fragments of this key tile, in registers
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            u[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[g2], pack8(pw + 8 * g2), u[dt], 0, 0, 0);
+            w[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[g2], pack8(pp + 8 * g2), w[dt], 0, 0, 0);
+          }
         }
       } else {
         const float* rowp = reinterpret_cast<const float*>(vs) + (32 * t + l31v) * 65 + half * 32;
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk)
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[kk], df.f[kk], dp, 0, 0, 0);
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dp[r] *= p[t][r];           // p * dp  (p = 0 on padded keys)
-        delta += dp[r];
+        for (int r = 0; r < 16; ++r) {
+          dp[r] *= p[t][r];
+          delta += dp[r];
+        }
+        contract_keys<T, NT>(ks, t, dp, u, l31v, half);
+        contract_keys<T, NT>(ks, t, p[t], w, l31v, half);
       }
-      contract_keys<T, NT>(kt, t, dp, u, l31v, half);
-      contract_keys<T, NT>(kt, t, p[t], w, l31v, half);
     }
     delta += __shfl_xor(delta, 32, 64);
+    __syncthreads();                               // everybody is done with the staged K / V
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        part_u[(wave * 8 + dt * 4 + g) * 64 + lane] = make_float4(u[dt][4 * g], u[dt][4 * g + 1], u[dt][4 * g + 2], u[dt][4 * g + 3]);
+        part_w[(wave * 8 + dt * 4 + g) * 64 + lane] = make_float4(w[dt][4 * g], w[dt][4 * g + 1], w[dt][4 * g + 2], w[dt][4 * g + 3]);
+      }
+    part_d[wave * 64 + lane] = delta;
+    __syncthreads();
+    const float dl = (part_d[lane] + part_d[64 + lane]) + (part_d[128 + lane] + part_d[192 + lane]);
     if (i < Kp) {
       T* orow = dq + prow * lddq + h * 64;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int gg = 0; gg < 2; ++gg) {
+        const int gi = wave * 2 + gg, dt = gi >> 2, g = gi & 3;
+        float4 us = make_float4(0.f, 0.f, 0.f, 0.f), ws = us;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float o4[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o4[j] = scale * (u[dt][4 * g + j] - delta * w[dt][4 * g + j]);
-          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o4[0], o4[1], o4[2], o4[3]);
+        for (int wv = 0; wv < 4; ++wv) {
+          const float4 a = part_u[(wv * 8 + gi) * 64 + lane], c = part_w[(wv * 8 + gi) * 64 + lane];
+          us.x += a.x; us.y += a.y; us.z += a.z; us.w += a.w;
+          ws.x += c.x; ws.y += c.y; ws.z += c.z; ws.w += c.w;
         }
+        ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, scale * (us.x - dl * ws.x), scale * (us.y - dl * ws.y),
+                      scale * (us.z - dl * ws.z), scale * (us.w - dl * ws.w));
+      }
     }
   }
 }

@@ -21,13 +21,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
-  float4 v[NV];
+  float4 v[NV], gm[NV], bt[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < nv4) {
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
+      gm[i] = *reinterpret_cast<const float4*>(gamma + 4 * c);   // issued with x: one memory round trip
+      bt[i] = *reinterpret_cast<const float4*>(beta + 4 * c);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
   }
@@ -47,8 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
-      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
+      const float4 g = gm[i], b = bt[i];
       ActIO<TY>::st4(yr + 4 * c, (v[i].x - mu) * rstd * g.x + b.x, (v[i].y - mu) * rstd * g.y + b.y,
                      (v[i].z - mu) * rstd * g.z + b.z, (v[i].w - mu) * rstd * g.w + b.w);
     }
@@ -80,16 +82,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
   const TDY* dyr = dy + (int64_t)row * lddy;
+  // every global load of the row (x, dy slabs, gamma) is issued before the first reduction: the row's
+  // lifetime is then ONE memory round trip plus four wave reductions (these launches are latency-bound)
   float4 v[NV], g[NV];
-  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < nv4) {
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      const float4 w = *reinterpret_cast<const float4*>(gamma + 4 * c);
+      float4 t = load4f<TDY>(dyr + 4 * c);
+      for (int sp = 1; sp < splits; ++sp) {     // split-K slabs, fixed order
+        const float4 t2 = load4f<TDY>(dyr + (int64_t)sp * split_stride + 4 * c);
+        t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
+      }
+      g[i] = make_float4(t.x * w.x, t.y * w.y, t.z * w.z, t.w * w.w);
     }
   }
+  float4 rr[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dres != nullptr && c < nv4) rr[i] = *reinterpret_cast<const float4*>(dres + (int64_t)row * lddres + 4 * c);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mu = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
@@ -106,14 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
-      const float4 w = *reinterpret_cast<const float4*>(gamma + 4 * c);
-      float4 t = load4f<TDY>(dyr + 4 * c);
-      for (int sp = 1; sp < splits; ++sp) {     // split-K slabs, fixed order
-        const float4 t2 = load4f<TDY>(dyr + (int64_t)sp * split_stride + 4 * c);
-        t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
-      }
       v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
-      g[i] = make_float4(t.x * w.x, t.y * w.y, t.z * w.z, t.w * w.w);
       sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
       sgx += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
     }
@@ -126,10 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     if (c < nv4) {
       float4 o = make_float4(rstd * (g[i].x - mg - v[i].x * mgx), rstd * (g[i].y - mg - v[i].y * mgx),
                              rstd * (g[i].z - mg - v[i].z * mgx), rstd * (g[i].w - mg - v[i].w * mgx));
-      if (dres != nullptr) {
-        const float4 r = *reinterpret_cast<const float4*>(dres + (int64_t)row * lddres + 4 * c);
-        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-      }
+      o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w;
       *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
       if (dxc != nullptr) ActIO<TC>::st4(dxc + (int64_t)row * ldc + 4 * c, o.x, o.y, o.z, o.w);
     }

@@ -32,7 +32,7 @@ from .config import RPOConfig
 SCALE = 1.0 / math.sqrt(64.0)
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
 # d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.
-SPLIT_FC, SPLIT_Q = 8, 4
+SPLIT_FC, SPLIT_Q = 4, 2     # measured best with 64x64 tiles (tools/bench_gemm.py): more slabs cost output bandwidth
 
 
 def _round_up(x: int, m: int) -> int:

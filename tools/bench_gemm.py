@@ -14,6 +14,16 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("c_proj", 7072, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
     ("bwd_du", 768, 3072, 768, EPI_QGELU_BWD, torch.bfloat16, 1),
     ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 8),
+    ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 2),
+    ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 3),
+    ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 4),
+    ("bwd_dh2", 768, 768, 3072, EPI_NONE, torch.float32, 6),
+    ("bwd_dh1", 768, 768, 768, EPI_NONE, torch.float32, 1),
+    ("bwd_dh1", 768, 768, 768, EPI_NONE, torch.float32, 2),
+    ("txt_dh2", 456, 512, 2048, EPI_NONE, torch.float32, 2),
+    ("txt_dh2", 456, 512, 2048, EPI_NONE, torch.float32, 4),
+    ("txt_dh1", 456, 512, 512, EPI_NONE, torch.float32, 1),
+    ("txt_dh1", 456, 512, 512, EPI_NONE, torch.float32, 2),
     ("bwd_da", 768, 768, 768, EPI_NONE, torch.bfloat16, 1),
     ("bwd_dh1", 768, 768, 768, EPI_NONE, torch.float32, 4),
     ("txt_q", 456, 512, 512, EPI_BIAS, torch.bfloat16, 1),
@@ -31,7 +41,7 @@ for name, M, N, K, epi, odt, split in SHAPES:
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
     res = []
-    cfgs = [2] + ([3] if epi in (EPI_BIAS, EPI_BIAS_QGELU) else [])
+    cfgs = [5]
     for cfg in [0] + cfgs:
         for _ in range(3):
             ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)
