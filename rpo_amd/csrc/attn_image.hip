@@ -204,36 +204,50 @@ __device__ __forceinline__ void rows_times_frag(const char* lds, const RowFrag<T
   }
 }
 
-// softmax over the keys held by this lane and its partner half (lane ^ 32); p normalised in place
+// softmax numerators over the keys held by this lane and its partner half (lane ^ 32); returns 1 / sum.
+// P is left UN-normalised (<= 1): the caller scales the 32 (64) output values instead of the NT*16 weights.
+// bf16 path: one fma + raw v_exp_f32 per element (arguments are <= 0, no range fix-up needed) and the
+// key >= N mask only on the tiles that can contain padding -- this loop was 30 % of the kernel
+// (s_memtime: 7.6 k of 25 k cycles) with the generic exp2f / per-element mask.
 template <typename T, int NT>
-__device__ __forceinline__ void softmax_rows(f32x16_t (&acc)[NT], int N, int half, float scale) {
+__device__ __forceinline__ float softmax_rows(f32x16_t (&acc)[NT], int N, int half, float scale) {
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    if (32 * t + 32 > N) {                       // uniform: tile may hold padded keys
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-      acc[t][r] = key < N ? acc[t][r] * scale : -INFINITY;
-      m = fmaxf(m, acc[t][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc[t][r] = key < N ? acc[t][r] : -INFINITY;
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[t][r]);
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float l = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    const float c = scale * LOG2E, mc = m * c;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float e;
-      if constexpr (sizeof(T) == 2) e = exp2f((acc[t][r] - m) * LOG2E);
-      else e = expf(acc[t][r] - m);
-      acc[t][r] = e;
-      l += e;
-    }
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c, -mc));
+        acc[t][r] = e;
+        l += e;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = expf((acc[t][r] - m) * scale);
+        acc[t][r] = e;
+        l += e;
+      }
+  }
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+  return 1.0f / l;
 }
 
 // o[dt] += M^T-contraction:  D[d][q] += sum_key M[key][d] * w[q][key], keys of tile t.
@@ -281,48 +295,67 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
   const T* vb = v + (int64_t)b * N * ld + h * 64;
   char* ks = smem;
   char* vs = smem + L::K_BYTES;
+  const int S = N + Kp;
+  RPO_STAMP(0);
+  // every HBM round trip of the prologue is issued up front: this wave's first query fragment, its V rows
+  // (bf16: the key tile it transposes), then the K staging loads
+  auto qrow = [&](int qt) -> int64_t {
+    const int sc = min(qt * 32 + l31, S - 1);
+    return sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
+  };
+  RowFrag<T> qf;
+  if constexpr (sizeof(T) == 2) qf.load(q + qrow(wave) * ld + h * 64, half);   // (f32: 32 live VGPRs too many)
   if constexpr (sizeof(T) == 2) {
-    stage_bf16<NT, 512, true, false>(ks, nullptr, kb, ld, N, tid);
-    // V^T fragments: wave w transposes key tiles w, w+8 on the matrix core, rows straight from HBM
-    const bf16x8_t i0 = ident_frag(0, l31, half), i1 = ident_frag(1, l31, half);
-    for (int t = wave; t < NT; t += 8) {
-      const int key = 32 * t + l31;
-      bf16x8_t rows[4];
+    bf16x8_t vrows[(NT + 7) / 8][4];
+#pragma unroll
+    for (int ti = 0; ti < (NT + 7) / 8; ++ti) {
+      const int key = 32 * (wave + 8 * ti) + l31;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         uint4 z = make_uint4(0, 0, 0, 0);
-        if (key < N) z = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ld + kk * 16 + half * 8);
-        rows[kk] = __builtin_bit_cast(bf16x8_t, z);
+        if (wave + 8 * ti < NT && key < N) z = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ld + kk * 16 + half * 8);
+        vrows[ti][kk] = __builtin_bit_cast(bf16x8_t, z);
       }
+    }
+    stage_bf16<NT, 512, true, false>(ks, nullptr, kb, ld, N, tid);
+    RPO_STAMP(1);
+    // V^T fragments: wave w transposes key tiles w, w+8 on the matrix core
+    const bf16x8_t i0 = ident_frag(0, l31, half), i1 = ident_frag(1, l31, half);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        bf16x8_t fr[2];
-        transpose_tile(rows, dt, i0, i1, fr);
+    for (int ti = 0; ti < (NT + 7) / 8; ++ti) {
+      const int t = wave + 8 * ti;
+      if (t < NT) {
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2)
-          *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t fr[2];
+          transpose_tile(vrows[ti], dt, i0, i1, fr);
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2)
+            *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
+        }
       }
     }
   } else {
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(ks), kb, ld, N, tid);
     stage_rows_f32<NT, 512>(reinterpret_cast<float*>(vs), vb, ld, N, tid);
   }
+  RPO_STAMP(2);
   __syncthreads();
+  RPO_STAMP(3);
 
-  const int S = N + Kp;
   for (int qt = wave; qt * 32 < S; qt += 8) {
     // K/V fragments in LDS do not depend on the query tile; without this opaque copy the
     // compiler hoists all of their ds_reads out of the loop and spills them to scratch
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
     const int s = qt * 32 + l31;
-    const int sc = min(s, S - 1);
-    const int64_t grow = sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
-    RowFrag<T> qf;
-    qf.load(q + grow * ld + h * 64, half);
+    const int64_t grow = qrow(qt);
+    if (sizeof(T) != 2 || qt != wave) qf.load(q + grow * ld + h * 64, half);
     f32x16_t acc[NT];
     rows_times_frag<T, NT>(ks, qf, acc, l31v, half);
-    softmax_rows<T, NT>(acc, N, half, scale);
+    RPO_STAMP(4);
+    const float inv = softmax_rows<T, NT>(acc, N, half, scale);
+    RPO_STAMP(5);
     f32x16_t o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -336,10 +369,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g], o[dt][4 * g + 1], o[dt][4 * g + 2],
-                        o[dt][4 * g + 3]);
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
+                        o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
     }
+    RPO_STAMP(6);
   }
+#ifdef RPO_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(7);
 }
 
 // ---- backward (prompt rows only; dq) -----------------------------------------------------
@@ -373,6 +411,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
   const int nqt = (Kp + 31) / 32;
   for (int qt = 0; qt < nqt; ++qt) {
     if (qt > 0) __syncthreads();                   // partials of the previous tile have been consumed
+    const int i = qt * 32 + l31;
+    const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
+    RowFrag<T> qf, df;                             // issued ahead of the staging loads: one HBM round trip
+    qf.load(qr + prow * ldq + h * 64, half);
+    df.load(da + prow * ldda + h * 64, half);
     if constexpr (sizeof(T) == 2) {
       stage_bf16<NT, 256, true, false>(ks, nullptr, kb, ldkv, N, tid);
       stage_bf16<NT, 256, true, false>(vs, nullptr, vb, ldkv, N, tid);
@@ -383,14 +426,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
     __syncthreads();
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
-    const int i = qt * 32 + l31;
-    const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
-    RowFrag<T> qf, df;
-    qf.load(qr + prow * ldq + h * 64, half);
-    df.load(da + prow * ldda + h * 64, half);
     f32x16_t p[NT];
     rows_times_frag<T, NT>(ks, qf, p, l31v, half);
-    softmax_rows<T, NT>(p, N, half, scale);
+    const float inv = softmax_rows<T, NT>(p, N, half, scale);   // p un-normalised; true P = p * inv
     f32x16_t u[2], w[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -416,8 +454,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
         float pw[16], pp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pp[r] = p[t][r];
-          pw[r] = dp[r] * pp[r];                   // p * dp  (p = 0 on padded keys)
+          pp[r] = p[t][r] * inv;
+          pw[r] = dp[r] * pp[r];                   // P * dP  (P = 0 on padded keys)
           delta += pw[r];
         }
 #pragma unroll
@@ -435,13 +473,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk)
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[kk], df.f[kk], dp, 0, 0, 0);
+        f32x16_t pn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          dp[r] *= p[t][r];
+          pn[r] = p[t][r] * inv;
+          dp[r] *= pn[r];
           delta += dp[r];
         }
         contract_keys<T, NT>(ks, t, dp, u, l31v, half);
-        contract_keys<T, NT>(ks, t, p[t], w, l31v, half);
+        contract_keys<T, NT>(ks, t, pn, w, l31v, half);
       }
     }
     delta += __shfl_xor(delta, 32, 64);

@@ -69,3 +69,16 @@ static inline int rpo_launch_status() {
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Optional in-kernel timeline (debug build with -DRPO_TIMELINE; tools/gemm_timeline.py, tools/attn_timeline.py):
+// thread 0 of a few workgroups stamps s_memtime at phase boundaries into a global buffer.
+#ifdef RPO_TIMELINE
+extern __device__ unsigned long long* g_timeline;
+#define RPO_STAMP(slot)                                                                               \
+  do {                                                                                                \
+    if (g_timeline != nullptr && threadIdx.x == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)   \
+      g_timeline[(blockIdx.x / 97) * 64 + (slot)] = __builtin_amdgcn_s_memtime();                     \
+  } while (0)
+#else
+#define RPO_STAMP(slot) do { } while (0)
+#endif

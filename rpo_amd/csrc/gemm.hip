@@ -47,21 +47,6 @@ struct GemmParams {
   int force_cfg;                       // 0 = heuristic; 2 = 128x128, 3 = 256x256 (benchmarking)
 };
 
-// Optional in-kernel timeline (build with -DRPO_GEMM_TIMELINE; tools/gemm_timeline.py): wave 0 of a few
-// workgroups stamps s_memtime at the phase boundaries into a global buffer set by rpo_debug_set_timeline.
-#ifdef RPO_GEMM_TIMELINE
-}  // namespace
-__device__ unsigned long long* g_timeline = nullptr;
-namespace {
-#define RPO_STAMP(slot)                                                                        \
-  do {                                                                                         \
-    if (g_timeline != nullptr && tid == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)    \
-      g_timeline[(blockIdx.x / 97) * 64 + (slot)] = __builtin_amdgcn_s_memtime();              \
-  } while (0)
-#else
-#define RPO_STAMP(slot) do { } while (0)
-#endif
-
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
 
 template <typename T> struct Tr;
@@ -96,7 +81,8 @@ template <> struct Tr<float> {
 //   CfgBig   256x256, 8 waves, 2 stages (128 KiB, 1 WG/CU): in-proj of the image forward.  A 128x128
 //            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU, which IS the L1/L2->CU rate, so it
 //            cannot pass ~50 % MFMA; 256x256 halves the bytes per flop.
-// (NSTAGE > 2 is supported by the counted-vmcnt loop below; a 4-stage 128x128 variant measured slower.)
+// (NSTAGE > 2 is supported by the counted-vmcnt loop below, but 3- and 4-stage 128x128 variants at one WG/CU
+//  measured 20-25 % slower than 2 stages at two WG/CU: the loop is bound by in-wave issue, not DMA latency.)
 template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_>
 struct Cfg {
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, NSTAGE = NSTAGE_;
@@ -179,16 +165,19 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   }
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto dma = [&](int stage, int kt) {
+  // one DMA instruction (1 KiB): piece i < DA belongs to the A tile, the rest to the W tile
+  auto dma_piece = [&](int stage, int kt, int i) {
     char* b_ = smem + stage * CF::STAGE_BYTES + wave * 1024;
     const int64_t ko = (int64_t)kt * KT_BYTES;
-#pragma unroll
-    for (int i = 0; i < CF::DA; ++i)
+    if (i < CF::DA)
       __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + ko), (lptr_t)(b_ + i * CF::NWAVES * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gptr_t)(gw[i - CF::DA] + ko),
+                                       (lptr_t)(b_ + CF::A_BYTES + (i - CF::DA) * CF::NWAVES * 1024), 16, 0, 0);
+  };
+  auto dma = [&](int stage, int kt) {
 #pragma unroll
-    for (int i = 0; i < CF::DW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + ko), (lptr_t)(b_ + CF::A_BYTES + i * CF::NWAVES * 1024), 16,
-                                       0, 0);
+    for (int i = 0; i < CF::DPT; ++i) dma_piece(stage, kt, i);
   };
 
   f32x16_t acc[CF::WN_T][CF::WM_T];
@@ -216,21 +205,37 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everybody is done with tile kt-1
     RPO_STAMP(2 + min(kt, 50));
-    if (kt + NSTAGE - 1 < nk) dma((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+    // The DMA of tile kt+NSTAGE-1 is issued piecewise BETWEEN the MFMA groups of tile kt.  Issuing one LDS-DMA
+    // costs the wave ~100 cycles; issued as a block right after the barrier, every wave of the workgroup pays
+    // that before its first MFMA and the matrix pipe idles (measured, one workgroup alone on the chip:
+    // ~1500 cycles per k-tile for 512 cycles of MFMA).  Interleaved, the issue hides behind running MFMAs.
+    const bool more = kt + NSTAGE - 1 < nk;
+    const int nstage = (kt + NSTAGE - 1) % NSTAGE, nkt = kt + NSTAGE - 1;
+    constexpr int PPS = (CF::DPT + T::KSTEPS - 1) / T::KSTEPS;   // pieces per k-step
     const char* st = smem + (kt % NSTAGE) * CF::STAGE_BYTES;
     const char* sx = st + rx * LROW;
     const char* sw = st + CF::A_BYTES + rwv * LROW;
+    // fragments are double-buffered in registers: the ds_reads of k-step ks+1 are in flight while the MFMAs
+    // of k-step ks run (static indices after unrolling)
+    typename T::frag_t xf[2][CF::WM_T], wf[2][CF::WN_T];
+    auto ldfrags = [&](int buf, int ks) {
+#pragma unroll
+      for (int tm = 0; tm < CF::WM_T; ++tm) xf[buf][tm] = T::ldfrag(sx + tm * 32 * LROW, swx, ks, half);
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn) wf[buf][tn] = T::ldfrag(sw + tn * 32 * LROW, sww, ks, half);
+    };
+    ldfrags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < T::KSTEPS; ++ks) {
-      typename T::frag_t xf[CF::WM_T], wf[CF::WN_T];
-#pragma unroll
-      for (int tm = 0; tm < CF::WM_T; ++tm) xf[tm] = T::ldfrag(sx + tm * 32 * LROW, swx, ks, half);
-#pragma unroll
-      for (int tn = 0; tn < CF::WN_T; ++tn) wf[tn] = T::ldfrag(sw + tn * 32 * LROW, sww, ks, half);
+      if (ks + 1 < T::KSTEPS) ldfrags((ks + 1) & 1, ks + 1);
 #pragma unroll
       for (int tn = 0; tn < CF::WN_T; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < CF::WM_T; ++tm) acc[tn][tm] = T::mfma(wf[tn], xf[tm], acc[tn][tm]);
+        for (int tm = 0; tm < CF::WM_T; ++tm) acc[tn][tm] = T::mfma(wf[ks & 1][tn], xf[ks & 1][tm], acc[tn][tm]);
+      if (more) {
+#pragma unroll
+        for (int i = ks * PPS; i < (ks + 1) * PPS && i < CF::DPT; ++i) dma_piece(nstage, nkt, i);
+      }
     }
   }
 
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
       }
     }
   }
-#ifdef RPO_GEMM_TIMELINE
+#ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RPO_STAMP(61);
@@ -421,7 +426,8 @@ int dispatch_f32out(int epi, const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-#ifdef RPO_GEMM_TIMELINE
+#ifdef RPO_TIMELINE
+__device__ unsigned long long* g_timeline = nullptr;
 extern "C" int rpo_debug_set_timeline(unsigned long long* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf));
 }

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""In-kernel phase timeline of rpo_attn_readonly_fwd (debug build with -DRPO_TIMELINE)."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rpo_amd import _lib, ops
+dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
+src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip")]
+os.makedirs(os.path.dirname(dbg), exist_ok=True)
+if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRPO_TIMELINE", "-fgpu-rdc", *src, "-o", dbg])
+lib = _lib.load(dbg); _lib._lib = lib
+lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
+dev = torch.device("cuda:0")
+buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
+assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
+B, H, N, Kp, d = 32, 12, 197, 24, 768
+qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
+out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
+for _ in range(3):
+    buf.zero_()
+    ops.attn_readonly_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], out, B, H, N, Kp)
+torch.cuda.synchronize()
+t = buf.view(8, 64).cpu()
+names = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "S^T done", "softmax done", "PV+store issued", "stores drained"]
+for b in range(4):
+    r = t[b]
+    if r[0] == 0: continue
+    print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[i-1])}" for i in range(1, 8)) + f" | total {int(r[7]-r[0])}")

@@ -9,15 +9,17 @@ from rpo_amd._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
 src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip")]
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRPO_GEMM_TIMELINE", *src, "-o", dbg])
+if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRPO_TIMELINE", "-fgpu-rdc", *src, "-o", dbg])
 lib = _lib.load(dbg)
 _lib._lib = lib
 lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
-for name, M, N, K, epi, odt, cfg in [("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 2), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 3),
-                                     ("txt_q", 456, 512, 512, EPI_BIAS, torch.bfloat16, 0), ("bwd_da", 768, 768, 768, EPI_NONE, torch.bfloat16, 0)]:
+for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), ("c_proj_deep4", 7072, 768, 3072, EPI_NONE, torch.float32, 7),
+                                     ("c_proj_tall", 7072, 768, 3072, EPI_NONE, torch.float32, 6), ("one_wg_mid", 128, 128, 3072, EPI_NONE, torch.float32, 2),
+                                     ("one_wg_deep", 128, 128, 3072, EPI_NONE, torch.float32, 7)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=odt, device=dev); bias = torch.randn(N, device=dev)
     for _ in range(3):
@@ -30,5 +32,5 @@ for name, M, N, K, epi, odt, cfg in [("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, t
         r = t[b]
         if r[0] == 0: continue
         nk = int((r[2:52] != 0).sum())
-        deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, nk)]
+        deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
         print(f" wg {b*97:5d}: start->tile0 {int(r[2]-r[0]):6d} | per-k-tile {deltas} | last-tile->epi {int(r[60]-r[2+nk-1]):6d} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}")
