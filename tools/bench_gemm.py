@@ -7,6 +7,7 @@ from rpo_amd import ops
 from rpo_amd._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_QGELU_BWD
 
 dev = torch.device("cuda:0")
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("qkv", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 1),
     ("out_proj", 7072, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
@@ -31,6 +32,8 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("txt_proj", 456, 512, 2048, EPI_BIAS_RESID, torch.float32, 1),
 ]
 for name, M, N, K, epi, odt, split in SHAPES:
+    if ONLY is not None and name != ONLY:
+        continue
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     out = torch.empty((split, M, N) if split > 1 else (M, N), dtype=odt, device=dev)
@@ -41,7 +44,7 @@ for name, M, N, K, epi, odt, split in SHAPES:
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
     res = []
-    cfgs = [2, 5, 6]
+    cfgs = [] if ONLY is not None else [2, 5, 6]
     for cfg in [0] + cfgs:
         for _ in range(3):
             ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)

@@ -17,24 +17,37 @@ if db:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n"
                 "# NB: kernel tracing serialises the two HIP queues; per-kernel durations are valid, overlap is not.\n")
         f.write(txt + "\n# last step:\n" + tl)
-names = {258048: "in-proj 7072x2304x768 (256x256 tiles)", 86016: "N=768 GEMMs (out_proj K=768 / c_proj K=3072; 128x128 tiles)",
-         344064: "c_fc 7072x3072x768 + QuickGELU (128x128 tiles)"}
-lines = ["# PMC counters per launch (mean over launches) for the forward GEMMs of the B=32 step, from separate\n"
-         "# `rocprofv3 --kernel-trace --pmc <set>` passes over tools/bench_gemm.py.  Grid_Size identifies the shape.\n"]
-for d in sorted(glob.glob(os.path.join(raw, "pmc_*"))):
-    if not os.path.isdir(d):
-        continue
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    if not f:
-        continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f[0])):
-        if "gemm_nt_kernel" in r["Kernel_Name"]:
-            agg[(int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    lines.append(f"\n## {os.path.basename(d)[4:]}\n")
-    for (grid, wg), v in sorted(agg.items(), reverse=True):
-        lines.append(f"grid {grid:7d} wg {wg:4d} {names.get(grid, ''):60s} " +
-                     "  ".join(f"{k}={sum(x) / len(x):.4g}" for k, x in sorted(v.items())) + "\n")
+SH = {"qkv": "in-proj 7072x2304x768 bias (256x256 tiles), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
+      "out_proj": "out-proj 7072x768x768 bias+residual (64x128 tiles), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
+      "c_fc": "c_fc 7072x3072x768 bias+QuickGELU (128x128 tiles), 33.4 GFLOP, 10.9+4.7+43.4 MB",
+      "c_proj": "c_proj 7072x768x3072 bias+residual (64x128 tiles), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
+lines = ["# PMC counters per launch (mean over launches) of the four forward GEMMs of one image-tower block at B=32,\n"
+         "# from separate `rocprofv3 --kernel-trace --pmc <set>` passes over `tools/bench_gemm.py --only <shape>`.\n"
+         "# FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x.\n"
+         "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs) = MFMA-pipe utilisation.\n"]
+for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
+    lines.append(f"\n## {SH[shape]}\n")
+    vals = {}
+    for d in sorted(glob.glob(os.path.join(raw, f"pmc_{shape}_*"))):
+        if not os.path.isdir(d):
+            continue
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "gemm_nt_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, x in agg.items():
+            vals[k] = sum(x) / len(x)
+    for k in sorted(vals):
+        lines.append(f"{k:32s} {vals[k]:.5g}\n")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
+        lines.append(f"{'-> MFMA pipe utilisation':32s} {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (vals['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
+    if "TCC_HIT_sum" in vals:
+        lines.append(f"{'-> L2 hit rate':32s} {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.3f}\n")
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        lines.append(f"{'-> HBM traffic (2*FETCH+WRITE)':32s} {(2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) / 1024:.1f} MB\n")
 open(os.path.join(out, f"{tag}_gemm_pmc.txt"), "w").writelines(lines)
 for fn in ("gemm_timeline.txt", "graph_phases.txt"):
     src = os.path.join(raw, fn)
