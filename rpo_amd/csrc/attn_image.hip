@@ -133,6 +133,34 @@ __device__ __forceinline__ void stage_bf16(char* dst_rows, char* dst_t, const bf
     }
   }
 }
+// K and V row-major staging with every global load of both matrices in flight before the first LDS write
+template <int NT, int NTHREADS>
+__device__ __forceinline__ void stage2_bf16(char* dk, char* dv, const bf16_t* sk, const bf16_t* sv, int64_t ld, int N,
+                                            int tid) {
+  constexpr int CHUNKS = NT * 32 * 8;
+  constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
+  uint4 a[ITERS], b[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * NTHREADS;
+    const int key = id >> 3, c = id & 7;
+    a[it] = make_uint4(0, 0, 0, 0);
+    b[it] = make_uint4(0, 0, 0, 0);
+    if (id < CHUNKS && key < N) {
+      a[it] = *reinterpret_cast<const uint4*>(sk + (int64_t)key * ld + c * 8);
+      b[it] = *reinterpret_cast<const uint4*>(sv + (int64_t)key * ld + c * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int id = tid + it * NTHREADS;
+    const int key = id >> 3, c = id & 7;
+    if (id < CHUNKS) {
+      *reinterpret_cast<uint4*>(dk + key * 144 + c * 16) = a[it];
+      *reinterpret_cast<uint4*>(dv + key * 144 + c * 16) = b[it];
+    }
+  }
+}
 template <int NT, int NTHREADS>
 __device__ __forceinline__ void stage_rows_f32(float* dst, const float* src, int64_t ld, int N, int tid) {
   constexpr int CHUNKS = NT * 32 * 16;
@@ -180,74 +208,61 @@ template <> struct RowFrag<float> {
   }
 };
 
-// acc[t] (+)= M[32t + i][:] . frag^T  -> D[i][q], M row-major in LDS (K or V)
-template <typename T, int NT>
-__device__ __forceinline__ void rows_times_frag(const char* lds, const RowFrag<T>& fr, f32x16_t (&acc)[NT],
-                                                int l31, int half) {
+// one 32x32 tile:  D[i][q] = M[32t + i][:] . frag[q][:]   (M = K or V rows, row-major in LDS)
+template <typename T>
+__device__ __forceinline__ f32x16_t tile_times_frag(const char* lds, int t, const RowFrag<T>& fr, int l31, int half) {
+  f32x16_t acc;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    const char* rowp = lds + (32 * t + l31) * 144 + half * 16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    if constexpr (sizeof(T) == 2) {
-      const char* rowp = lds + (32 * t + l31) * 144 + half * 16;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 32);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.f[ks], acc[t], 0, 0, 0);
-      }
-    } else {
-      const float* rowp = reinterpret_cast<const float*>(lds) + (32 * t + l31) * 65 + half * 32;
-#pragma unroll
-      for (int ks = 0; ks < 32; ++ks)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[ks], fr.f[ks], acc[t], 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 32);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.f[ks], acc, 0, 0, 0);
     }
+  } else {
+    const float* rowp = reinterpret_cast<const float*>(lds) + (32 * t + l31) * 65 + half * 32;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[ks], fr.f[ks], acc, 0, 0, 0);
   }
+  return acc;
 }
 
-// softmax numerators over the keys held by this lane and its partner half (lane ^ 32); returns 1 / sum.
-// P is left UN-normalised (<= 1): the caller scales the 32 (64) output values instead of the NT*16 weights.
-// bf16 path: one fma + raw v_exp_f32 per element (arguments are <= 0, no range fix-up needed) and the
-// key >= N mask only on the tiles that can contain padding -- this loop was 30 % of the kernel
-// (s_memtime: 7.6 k of 25 k cycles) with the generic exp2f / per-element mask.
-template <typename T, int NT>
-__device__ __forceinline__ float softmax_rows(f32x16_t (&acc)[NT], int N, int half, float scale) {
-  float m = -INFINITY;
+// keys >= N of tile t -> -inf (only tiles that can hold padding pay for the compare), then the tile's row
+// maximum over both lane halves.  A lane holds one query's scores for 16 of the tile's 32 keys.
+__device__ __forceinline__ float mask_and_max(f32x16_t& s, int t, int N, int half) {
+  if (32 * t + 32 > N) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (32 * t + 32 > N) {                       // uniform: tile may hold padded keys
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc[t][r] = key < N ? acc[t][r] : -INFINITY;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+      s[r] = key < N ? s[r] : -INFINITY;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[t][r]);
   }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float m = s[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) m = fmaxf(m, s[r]);
+  return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+
+// s <- exp((s - m) * scale) element-wise; returns this lane's partial row sum.
+// bf16 path: one fma + raw v_exp_f32 per element (arguments <= 0: no range fix-up needed).
+template <typename T>
+__device__ __forceinline__ float exp_tile(f32x16_t& s, float m, float scale) {
   float l = 0.f;
   if constexpr (sizeof(T) == 2) {
     const float c = scale * LOG2E, mc = m * c;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(acc[t][r], c, -mc));
-        acc[t][r] = e;
-        l += e;
-      }
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc)); l += s[r]; }
   } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = expf((acc[t][r] - m) * scale);
-        acc[t][r] = e;
-        l += e;
-      }
+    for (int r = 0; r < 16; ++r) { s[r] = expf((s[r] - m) * scale); l += s[r]; }
   }
-  l += __shfl_xor(l, 32, 64);
-  return 1.0f / l;
+  return l;
+}
+template <typename T> __device__ __forceinline__ float exp_scalar(float d, float scale) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(d * scale * LOG2E);
+  else return expf(d * scale);
 }
 
 // o[dt] += M^T-contraction:  D[d][q] += sum_key M[key][d] * w[q][key], keys of tile t.
@@ -283,7 +298,7 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
 
 // ---- forward ---------------------------------------------------------------------------
 template <typename T, int NT>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, int64_t ld, T* out,
                                                        int64_t ldo, int B, int H, int N, int Kp, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -351,18 +366,30 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
     const int s = qt * 32 + l31;
     const int64_t grow = qrow(qt);
     if (sizeof(T) != 2 || qt != wave) qf.load(q + grow * ld + h * 64, half);
-    f32x16_t acc[NT];
-    rows_times_frag<T, NT>(ks, qf, acc, l31v, half);
-    RPO_STAMP(4);
-    const float inv = softmax_rows<T, NT>(acc, N, half, scale);
-    RPO_STAMP(5);
+    // online softmax over the key tiles (running max m, running sum l, output rescaled when m grows): only one
+    // score tile is live, so the kernel fits 128 VGPRs and TWO workgroups share a CU -- the 384 (image, head)
+    // workgroups of a B=32 launch are then all resident at once instead of running in two rounds.
+    float m = -INFINITY, l = 0.f;
     f32x16_t o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
+      const float mn = fmaxf(m, mask_and_max(sc, t, N, half));     // finite from tile 0 on (N >= 1)
+      const float alpha = exp_scalar<T>(m - mn, scale);           // first tile: exp(-inf) = 0
+      l = l * alpha + exp_tile<T>(sc, mn, scale);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) contract_keys<T, NT>(vs, t, acc[t], o, l31v, half);
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      contract_keys<T, NT>(vs, t, sc, o, l31v, half);
+      m = mn;
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
     if (s < S) {
       T* orow = out + grow * ldo + h * 64;
 #pragma unroll
@@ -387,7 +414,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const T* __restrict__ q, 
 // statistics, then takes the key tiles t = wave, wave+4, ... for dP / U / W; partial U, W, delta are
 // combined through LDS (the staging area is dead by then).
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
                                                        const T* __restrict__ k, const T* __restrict__ v,
                                                        int64_t ldkv, const T* __restrict__ da, int64_t ldda,
                                                        T* dq, int64_t lddq, int B, int H, int N, int Kp,
@@ -417,8 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
     qf.load(qr + prow * ldq + h * 64, half);
     df.load(da + prow * ldda + h * 64, half);
     if constexpr (sizeof(T) == 2) {
-      stage_bf16<NT, 256, true, false>(ks, nullptr, kb, ldkv, N, tid);
-      stage_bf16<NT, 256, true, false>(vs, nullptr, vb, ldkv, N, tid);
+      stage2_bf16<NT, 256>(ks, vs, kb, vb, ldkv, N, tid);          // K and V loads in ONE round trip
     } else {
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
@@ -426,35 +452,40 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
     __syncthreads();
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
-    f32x16_t p[NT];
-    rows_times_frag<T, NT>(ks, qf, p, l31v, half);
-    const float inv = softmax_rows<T, NT>(p, N, half, scale);   // p un-normalised; true P = p * inv
+    // phase 1 (every wave, 4 MFMAs per tile): row max and sum of the scores, online -- nothing else is kept,
+    // which keeps the kernel at two workgroups per CU (all 384 (image, head) workgroups resident at once)
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
+      const float mn = fmaxf(m, mask_and_max(sc, t, N, half));
+      l = l * exp_scalar<T>(m - mn, scale) + exp_tile<T>(sc, mn, scale);
+      m = mn;
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // phase 2: this wave's key tiles t = wave, wave+4, ...
     f32x16_t u[2], w[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { u[dt][r] = 0.f; w[dt][r] = 0.f; }
     float delta = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if ((t & 3) != wave) continue;               // wave-uniform
-      f32x16_t dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll 1
+    for (int t = wave; t < NT; t += 4) {           // wave-uniform trip count
+      f32x16_t pt = tile_times_frag<T>(ks, t, qf, l31v, half);
+      (void)mask_and_max(pt, t, N, half);
+      (void)exp_tile<T>(pt, m, scale);
+      f32x16_t dp = tile_times_frag<T>(vs, t, df, l31v, half);
       if constexpr (sizeof(T) == 2) {
-        const char* vrow = vs + (32 * t + l31v) * 144 + half * 16;
         const char* krow = ks + (32 * t + l31v) * 144 + half * 16;
         bf16x8_t krows[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vrow + kk * 32);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, df.f[kk], dp, 0, 0, 0);
-          krows[kk] = *reinterpret_cast<const bf16x8_t*>(krow + kk * 32);
-        }
+        for (int kk = 0; kk < 4; ++kk) krows[kk] = *reinterpret_cast<const bf16x8_t*>(krow + kk * 32);
         float pw[16], pp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pp[r] = p[t][r] * inv;
+          pp[r] = pt[r] * inv;
           pw[r] = dp[r] * pp[r];                   // P * dP  (P = 0 on padded keys)
           delta += pw[r];
         }
@@ -469,14 +500,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qr,
           }
         }
       } else {
-        const float* rowp = reinterpret_cast<const float*>(vs) + (32 * t + l31v) * 65 + half * 32;
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk)
-          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[kk], df.f[kk], dp, 0, 0, 0);
         f32x16_t pn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pn[r] = p[t][r] * inv;
+          pn[r] = pt[r] * inv;
           dp[r] *= pn[r];
           delta += dp[r];
         }

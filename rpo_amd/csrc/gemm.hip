@@ -239,6 +239,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     }
   }
 
+
   RPO_STAMP(60);
   // ---- epilogue, staged through LDS -------------------------------------------------------------
   // acc[tn][tm] holds D[n][m] (lane: m = l31, n = 8*g + 4*half + j, reg = 4*g + j).  Storing straight from
