@@ -113,6 +113,26 @@ def time_dominant_kernel(trainer, batch: int, iters: int = 30):
             "achieved": round(fl / us / 1e6, 1), "unit": "TFLOP/s"}
 
 
+def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
+    """CustomCLIP eval branch (trainers/rpo.py:229-232) at the reference's test batch
+    (configs/trainers/RPO/main_K24.yaml:5), text features computed once instead of per batch."""
+    from rpo_amd.custom_clip import CustomCLIP
+    m = CustomCLIP(cfg, sd, toks, dev, act, max_batch=batch, prompts=prompts)
+    m.prompt_learner.eval()
+    img = torch.from_numpy(synth.images(cfg, batch, seed=77)).to(dev)
+    for _ in range(3):
+        m(img)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        m.engine.forward_eval(img)
+    e.record()
+    e.synchronize()
+    ms = s.elapsed_time(e) / iters
+    return {"batch": batch, "ms_per_batch": round(ms, 3), "images_per_sec": round(1e3 * batch / ms, 1),
+            "note": "eager launches (no graph); text tower skipped after the first batch"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +144,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-batch", type=int, default=0,
+                    help="also time the eval branch (logits only, text features cached) at this batch size")
     args = ap.parse_args()
 
     sync = GradSync()                                    # reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
@@ -187,10 +209,13 @@ def main() -> None:
     if sync.rank == 0:
         out["roofline"]["dominant_kernel"] = time_dominant_kernel(tr, args.batch)
         out["hbm_resident_gb"] = round(tr.engine.hbm_bytes() / 2 ** 30, 2)
+        if args.eval_batch > 0:
+            out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)
         if sync.world_size == 1 and not args.no_cpu_baseline:
             full = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
             out["cpu_baseline"] = cpu_baseline(cfg, full, toks, prompts)
         print(json.dumps(out), flush=True)
+    sync.barrier()                                       # nobody tears the process group down while rank 0 works
     sync.close()
 
 

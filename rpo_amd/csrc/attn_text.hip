@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void text_attn_kernel(const T* __restrict__ q,
   }
   __syncthreads();
   const int j0 = min(lane, Lmax - 1), j1 = min(lane + 64, Lmax - 1);
-  for (int r = wave; r < rows; r += 4) {
+  // one query row per wave; blockIdx.y walks the rows in chunks of 4 (each chunk re-stages the tiny K/V
+  // slices): a row is ~1.5 k VALU instructions, so spreading rows over workgroups is what shortens the launch
+  for (int r = blockIdx.y * 4 + wave; r < rows; r += 4 * gridDim.y) {
     const int64_t row = (int64_t)c * rows + r;
     const int nk = causal ? min(r + 1, L) : L;
     const float qv = ActIO<T>::ld(q + row * ldq + h * 64 + lane);
@@ -127,7 +129,7 @@ int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t l
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_cls * H), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
+  hipLaunchKernelGGL(kern, dim3(n_cls * H, (rows + 3) / 4), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
                      static_cast<const T*>(kc), static_cast<const T*>(vc), ldkv, static_cast<const T*>(da), ldda,
                      static_cast<T*>(out), ldo, len, rows, Lmax, H, causal, scale);
   return rpo_launch_status();

@@ -76,4 +76,9 @@ class CustomCLIP(nn.Module):
             tp, ip = self.prompt_learner()
             return _StepFunction.apply(tp, ip, self.engine, image, label)
         with torch.no_grad():
+            # prompts may have been edited through the nn.Parameter views: a cheap version key
+            ver = (self.prompt_learner.text_prompt._version, self.prompt_learner.img_prompt._version)
+            if ver != getattr(self, "_seen_version", None):
+                self.engine.params_version += 1
+                self._seen_version = ver
             return self.engine.forward_eval(image).clone()

@@ -27,7 +27,9 @@ class GradSync:
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.enabled = self.world_size > 1
+        # RPO_FORCE_DIST=1 runs the collective path even with one rank (exercises RCCL init / all-reduce /
+        # barrier on a single-GPU box; the numbers are unchanged: sum over one rank, scale 1)
+        self.enabled = self.world_size > 1 or os.environ.get("RPO_FORCE_DIST") == "1"
         if self.enabled and init and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -71,6 +71,8 @@ class Engine:
         self._pack(state_dict, tokens)
         self._alloc()
         self.text_cache_ready = False
+        self.text_f_version = -1        # prompts version the cached eval text features belong to
+        self.params_version = 0         # bumped by whoever changes the prompts (optimiser step, load)
 
     # ------------------------------------------------------------------ weights
     def _f32(self, a: np.ndarray) -> torch.Tensor:
@@ -325,11 +327,17 @@ class Engine:
         """logits[B, n_cls] (trainers/rpo.py:232)."""
         B = self._check(image)
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self._text_forward(train=False)
+        # text features depend on the prompts only: in evaluation they are computed once, not per batch
+        # (the reference recomputes the text tower for every test batch, SURVEY.md section 3.4)
+        text_stale = self.text_f_version != self.params_version
+        if text_stale:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._text_forward(train=False)
         self._image_forward(image, train=False)
-        main.wait_stream(self.side)
+        if text_stale:
+            main.wait_stream(self.side)
+            self.text_f_version = self.params_version
         K, e = self.cfg.K, self.cfg.embed
         ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(self.cfg.n_cls, K, e), None,
                          self.logit_scale_exp, self.logits[:B], None, None, None, self.head_ws)
@@ -339,6 +347,7 @@ class Engine:
         """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in
         self.loss, self.logits, self.grads (= [g_text | g_img]).  Capturable in a HIP graph."""
         B = self._check(image)
+        self.text_f_version = -1
         assert label.dtype == torch.int64 and label.shape == (B,)
         K, e, n = self.cfg.K, self.cfg.embed, self.cfg.n_cls
         main = torch.cuda.current_stream()

@@ -155,6 +155,8 @@ class RPO:
         ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
                      self.sync.grad_scale, first_step=(self._steps == 0))
         self._steps += 1
+        eng.params_version += 1
+        eng.text_f_version = -1
         return eng.loss
 
     def update_lr(self) -> None:
@@ -201,5 +203,6 @@ class RPO:
         if "momentum" in ck:
             self.engine.mom.copy_(ck["momentum"])
             self._steps = int(ck.get("steps", 1))
+        self.engine.params_version += 1
         self.epoch = int(ck.get("epoch", 0))
         self.lr = lr_at_epoch(self.optim_cfg, self.epoch)

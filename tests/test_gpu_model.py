@@ -214,3 +214,27 @@ def test_vit_l14_dims_against_oracle(act, tol):
         assert el <= tol and rt <= tol and ri <= tol
     else:
         assert el <= 0.1 and rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL
+
+
+def test_bench_runs_under_torchrun_with_rccl(tmp_path):
+    """The launch line the driver uses for N > 1, with one rank (this box has one GPU): RCCL process group,
+    prompt broadcast, gradient all-reduce and barriers all execute (RPO_FORCE_DIST=1)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RPO_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert np.isfinite(d["config"]["final_loss"])
