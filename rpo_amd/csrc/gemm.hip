@@ -196,14 +196,26 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) dma(s, s);
 
+#ifdef RPO_TIMELINE
+  unsigned long long t_wait = 0, t_bar = 0, t_body = 0, t_a, t_b, t_c, t_d;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef RPO_TIMELINE
+    t_a = __builtin_amdgcn_s_memtime();
+#endif
     // tiles already issued: up to kt + NSTAGE - 2; tile kt must have landed
     const int ahead = min(kt + NSTAGE - 2, nk - 1) - kt;
     if (NSTAGE == 2 || ahead <= 0) wait_vmcnt<0>();
     else if (ahead == 1) wait_vmcnt<CF::DPT>();
     else if (NSTAGE > 3 && ahead == 2) wait_vmcnt<2 * CF::DPT>();
     else wait_vmcnt<0>();
+#ifdef RPO_TIMELINE
+    t_b = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everybody is done with tile kt-1
+#ifdef RPO_TIMELINE
+    t_c = __builtin_amdgcn_s_memtime();
+#endif
     RPO_STAMP(2 + min(kt, 50));
     // The DMA of tile kt+NSTAGE-1 is issued piecewise BETWEEN the MFMA groups of tile kt.  Issuing one LDS-DMA
     // costs the wave ~100 cycles; issued as a block right after the barrier, every wave of the workgroup pays
@@ -237,7 +249,18 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
         for (int i = ks * PPS; i < (ks + 1) * PPS && i < CF::DPT; ++i) dma_piece(nstage, nkt, i);
       }
     }
+#ifdef RPO_TIMELINE
+    t_d = __builtin_amdgcn_s_memtime();
+    t_wait += t_b - t_a; t_bar += t_c - t_b; t_body += t_d - t_c;
+#endif
   }
+#ifdef RPO_TIMELINE
+  if (g_timeline != nullptr && tid == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) {
+    g_timeline[(blockIdx.x / 97) * 64 + 53] = t_wait;
+    g_timeline[(blockIdx.x / 97) * 64 + 54] = t_bar;
+    g_timeline[(blockIdx.x / 97) * 64 + 55] = t_body;
+  }
+#endif
 
 
   RPO_STAMP(60);

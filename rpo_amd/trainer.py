@@ -93,7 +93,8 @@ class RPO:
         torch.cuda.synchronize()                                # builds the text K/V cache
         def cap(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):               # a graph replays on whatever stream is current at replay()
+            # thread_local: the RCCL watchdog thread of a data-parallel run may query events while we capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # replays on the stream current at replay()
                 fn()
             return g
 

@@ -17,9 +17,9 @@ lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
-for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), ("c_proj_deep4", 7072, 768, 3072, EPI_NONE, torch.float32, 7),
+for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), 
                                      ("c_proj_tall", 7072, 768, 3072, EPI_NONE, torch.float32, 6), ("one_wg_mid", 128, 128, 3072, EPI_NONE, torch.float32, 2),
-                                     ("one_wg_deep", 128, 128, 3072, EPI_NONE, torch.float32, 7)]:
+                                     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 0)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=odt, device=dev); bias = torch.randn(N, device=dev)
     for _ in range(3):
@@ -33,4 +33,4 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
         if r[0] == 0: continue
         nk = int((r[2:52] != 0).sum())
         deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
-        print(f" wg {b*97:5d}: start->tile0 {int(r[2]-r[0]):6d} | per-k-tile {deltas} | last-tile->epi {int(r[60]-r[2+nk-1]):6d} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}")
+        print(f" wg {b*97:5d}: start->tile0 {int(r[2]-r[0]):6d} | per-k-tile {deltas} | last-tile->epi {int(r[60]-r[2+nk-1]):6d} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])} || wave0 per-iter: vmcnt-wait {int(r[53])//max(nk,1)} barrier {int(r[54])//max(nk,1)} body(issue) {int(r[55])//max(nk,1)}")
