@@ -35,10 +35,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 template <typename T, int NT> struct AL;  // LDS layout
 template <int NT> struct AL<bf16_t, NT> {
   static constexpr int NPAD = NT * 32;
-  static constexpr int KROW = 144;                 // bytes per K (or row-major V) row
-  static constexpr int TROW = (NPAD + 4) * 2;      // bytes per transposed row
+  static constexpr int KROW = 144;                 // bytes per K (or row-major V) row: 128 + 16 pad
   static constexpr int K_BYTES = NPAD * KROW;
-  static constexpr int T_BYTES = 64 * TROW;
   static constexpr int F_BYTES = NT * 4 * 1024;                  // V^T fragments: [NT][2 dt][2 g2][64 lanes][16 B]
   static constexpr int PART_BYTES = 4 * 16 * 64 * 16 + 4 * 64 * 4;  // backward cross-wave partials
   static constexpr int FWD_BYTES = K_BYTES + F_BYTES;            // Ks | Vfrag
@@ -102,12 +100,10 @@ __device__ __forceinline__ void transpose_tile(const bf16x8_t (&rows)[4], int dt
 // All global loads of a pass are issued before the first LDS write (fully unrolled, static
 // register indices): a load-use-per-iteration loop serialises one HBM round trip per iteration
 // and was the dominant cost of these kernels.
-template <int NT, int NTHREADS, bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_bf16(char* dst_rows, char* dst_t, const bf16_t* src, int64_t ld, int N,
-                                           int tid) {
+template <int NT, int NTHREADS>
+__device__ __forceinline__ void stage_rows_bf16(char* dst, const bf16_t* src, int64_t ld, int N, int tid) {
   constexpr int CHUNKS = NT * 32 * 8;
   constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
-  constexpr int TROW = AL<bf16_t, NT>::TROW;
   uint4 v[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -120,17 +116,7 @@ __device__ __forceinline__ void stage_bf16(char* dst_rows, char* dst_t, const bf
   for (int it = 0; it < ITERS; ++it) {
     const int id = tid + it * NTHREADS;
     const int key = id >> 3, c = id & 7;
-    if (id < CHUNKS) {
-      if (ROWMAJOR) *reinterpret_cast<uint4*>(dst_rows + key * 144 + c * 16) = v[it];
-      if (TRANSPOSED) {
-        const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bf16_t e = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-          *reinterpret_cast<bf16_t*>(dst_t + (c * 8 + j) * TROW + key * 2) = e;
-        }
-      }
-    }
+    if (id < CHUNKS) *reinterpret_cast<uint4*>(dst + key * 144 + c * 16) = v[it];
   }
 }
 // K and V row-major staging with every global load of both matrices in flight before the first LDS write
@@ -332,7 +318,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
         vrows[ti][kk] = __builtin_bit_cast(bf16x8_t, z);
       }
     }
-    stage_bf16<NT, 512, true, false>(ks, nullptr, kb, ld, N, tid);
+    stage_rows_bf16<NT, 512>(ks, kb, ld, N, tid);
     RPO_STAMP(1);
     // V^T fragments: wave w transposes key tiles w, w+8 on the matrix core
     const bf16x8_t i0 = ident_frag(0, l31, half), i1 = ident_frag(1, l31, half);

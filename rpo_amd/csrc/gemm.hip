@@ -3,33 +3,35 @@
 // Replaces nn.Linear / the packed in-proj and out-proj matmuls of nn.MultiheadAttention
 // (reference clip/model.py:171-177,186) and, in the backward, autograd's dX = dY . W.
 //
-// Tiling: 128x128 block tile, 4 waves in 2x2, each wave a 64x64 sub-tile as 2x2 MFMA 32x32
-// tiles.  bf16: v_mfma_f32_32x32x16_bf16, k-tile 64.  f32 (parity mode):
-// v_mfma_f32_32x32x2_f32 (exact f32 fma chain), k-tile 32.  Both k-tiles are 128 B per row.
+// bf16: v_mfma_f32_32x32x16_bf16, k-tile 64.  f32 (parity mode): v_mfma_f32_32x32x2_f32 (exact f32 fma
+// chain), k-tile 32.  Both k-tiles are 128 B per row.  Tile shapes (Cfg below) are chosen per GEMM shape.
 //
-// Staging is direct HBM->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): no
-// staging VGPRs and, decisive on this kernel, no ds_write pass -- with register staging the
-// eight ds_write_b128 per thread per k-tile (13 LDS cycles each) plus the fragment reads
-// exceeded the MFMA time of the tile, i.e. the loop was LDS-bound.  The DMA writes LDS
-// lane-linearly (wave-uniform base + lane*16), so rows are an unpadded 128 B and the
-// bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE address and again on the
-// fragment read (guide rule 21): 16-B chunk c of row r lives at chunk c ^ ((r >> 1) & 7).
-// For the 16-lane groups of ds_read_b128 this gives 16 distinct 16-B slots.
-// Double-buffered, one barrier per k-tile; the DMA of tile t+1 is in flight during the MFMAs
-// of tile t and is drained (vmcnt(0)) right before the barrier.
+// Staging is direct HBM->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): no staging VGPRs, no
+// ds_write pass.  (A register-staged variant -- global_load_dwordx4 + swizzled ds_write_b128 -- measured
+// 10-15 % slower at every forward shape.)  The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so
+// rows are an unpadded 128 B and the bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE
+// address and again on the fragment read (guide rule 21): 16-B chunk c of row r lives at chunk
+// c ^ ((r >> 1) & 7), which gives the 16-lane groups of ds_read_b128 16 distinct 16-B slots
+// (SQ_LDS_BANK_CONFLICT = 0 in the main loop).
+// Two LDS stages, one raw s_barrier per k-tile with a counted vmcnt; the DMA of tile t+1 is issued piecewise
+// between the MFMA groups of tile t and operand fragments are double-buffered in registers.  In-kernel
+// s_memtime stamps (tools/gemm_timeline.py) show what bounds the loop: a wave spends ~1.1-1.6 k cycles issuing
+// one k-tile's body for 256 cycles of its own MFMAs -- an LDS-DMA costs ~100 issue cycles -- so the matrix pipe
+// runs at ~50 % inside the loop, and with K = 768 only 12 tiles deep ~35 % of a workgroup's life is prologue
+// (first DMA round trip) and epilogue (store drain).  Deeper pipelines (3/4 stages at one workgroup per CU)
+// were 20-25 % slower: the limit is in-wave issue, not DMA latency.
 //
 // The weight tile is the MFMA *A* operand and the activation tile the *B* operand, i.e. the
 // wave computes D[n][m]: by the 32x32 C/D map (col = lane&31, row = (reg&3)+8*(reg>>2)+
-// 4*(lane>>5)) each lane then owns 4 CONSECUTIVE n for one m per register quad, which
-// turns the epilogue's bias / residual loads and the stores into 16-B (f32) / 8-B (bf16)
-// vector accesses on row-major C.  The contraction index needs no particular lane order:
-// both operands are read with the same (k-step, lane>>5) -> k mapping, so any hardware
-// k-permutation cancels.
+// 4*(lane>>5)) each lane then owns 4 CONSECUTIVE n for one m per register quad.  The contraction index
+// needs no particular lane order: both operands are read with the same (k-step, lane>>5) -> k mapping,
+// so any hardware k-permutation cancels.
 //
 // Workgroup ids are remapped so that each XCD (block b runs on XCD b % 8) owns a contiguous
-// range of tiles and re-reads its A / W panels from its own L2.  Optional split-K
-// (gridDim.y slices, each writing its own fp32 slab; the consumer sums the slabs in a fixed
-// order) keeps the long-K, few-tile dX GEMMs of the backward from running on 36 CUs.
+// range of tiles, walked in groups of 8 m-tiles so the co-resident workgroups of an XCD share their
+// A / W panels in its 4 MiB L2.  Optional split-K (gridDim.y slices, each writing its own fp32 slab; the
+// consumer sums the slabs in a fixed order, no atomics) keeps the long-K, few-tile dX GEMMs of the
+// backward from running on a handful of CUs.
 #include "common.h"
 
 namespace {
@@ -44,7 +46,7 @@ struct GemmParams {
   float* aux; int64_t ldaux; int aux_row0;
   int skip_row0, skip_col0, group;
   int split_k; int64_t split_stride;   // elements of C between slabs
-  int force_cfg;                       // 0 = heuristic; 2 = 128x128, 3 = 256x256 (benchmarking)
+  int force_cfg;                       // 0 = heuristic; 2/3/5/6 force a tile shape (benchmarking)
 };
 
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
