@@ -238,3 +238,73 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert np.isfinite(d["config"]["final_loss"])
+
+
+@pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1)])
+def test_edge_shapes_against_oracle_f32(K, n_cls, B):
+    """K = 1 (reference asserts K >= 1), a class count that is not 19, the largest K that still fits the
+    context next to the longest prompt (len 24 -> K = 53), batch 1."""
+    from oracle.rpo_oracle import OracleRPO
+    from rpo_amd.config import vit_b16
+    from rpo_amd.custom_clip import CustomCLIP
+    cfg = vit_b16(layers_v=1, layers_t=1, K=K, n_cls=n_cls)
+    lens = [3 + (7 * c) % 22 for c in range(n_cls)]
+    lens[0] = 24 if K == 53 else lens[0]
+    toks = synth.synthetic_tokens(cfg, lens)
+    sd = synth.clip_state_dict(cfg, seed=2, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=4)
+    image, label = synth.images(cfg, B), synth.labels(cfg, B)
+    o = OracleRPO(sd, toks, cfg.K, cfg.patch)
+    o.set_prompts(tp, ip)
+    out, gt, gi = o.loss_and_grads(image, label)
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float32, max_batch=B, prompts=(tp, ip))
+    loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    loss.backward()
+    assert abs(loss.item() - out.loss.item()) <= TOL_F32
+    assert _relmax(m.prompt_learner.text_prompt.grad.cpu().numpy(), gt.numpy()) <= TOL_F32
+    assert _relmax(m.prompt_learner.img_prompt.grad.cpu().numpy(), gi.numpy()) <= TOL_F32
+    m.prompt_learner.eval()
+    np.testing.assert_allclose(m(torch.from_numpy(image).cuda()).cpu().numpy(), out.logits.detach().numpy(), atol=TOL_F32)
+
+
+@pytest.mark.parametrize("act", [torch.float32, torch.bfloat16])
+def test_full_size_properties(act):
+    """BASELINE.json configs[1] at full size (12 layers, K=24, B=32), where the CPU oracle is too slow to be the
+    checker: size-independent properties of the step instead."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.trainer import RPO
+    cfg = vit_b16()
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    B = 32
+    img = torch.from_numpy(synth.images(cfg, B)).cuda()
+    lab = torch.from_numpy(synth.labels(cfg, B)).cuda()
+    tr = RPO(cfg, sd, toks, None, "cuda:0", act, batch_size=B, prompts=(tp, ip))
+    eng = tr.engine
+    # (1) determinism: the same batch twice -> bit-identical loss and gradients
+    eng.forward_backward(img, lab); torch.cuda.synchronize()
+    g0, l0, lg0 = eng.grads.clone(), eng.loss.clone(), eng.logits.clone()
+    eng.forward_backward(img, lab); torch.cuda.synchronize()
+    assert torch.equal(eng.grads, g0) and torch.equal(eng.loss, l0)
+    assert torch.isfinite(g0).all() and torch.isfinite(l0).all()
+    # (2) the eval branch returns the logits the train step computed
+    tr.model.prompt_learner.eval()
+    lg_eval = tr.model(img)
+    tr.model.prompt_learner.train()
+    assert torch.equal(lg_eval, lg0)
+    # (3) loss = mean CE of those logits (fp32 head): recompute on the host
+    ce = torch.nn.functional.cross_entropy(lg0.double().cpu(), lab.cpu()).item()
+    assert abs(ce - l0.item()) <= 1e-5 * max(1.0, abs(ce))
+    # (4) linearity of mean-CE gradients in the batch: g(32) == (g(first 16) + g(last 16)) / 2
+    eng.forward_backward(img[:16].contiguous(), lab[:16].contiguous()); torch.cuda.synchronize()
+    ga = eng.grads.clone()
+    eng.forward_backward(img[16:].contiguous(), lab[16:].contiguous()); torch.cuda.synchronize()
+    gb = eng.grads.clone()
+    rel = ((ga + gb) / 2 - g0).abs().max().item() / g0.abs().max().item()
+    assert rel <= (2e-5 if act == torch.float32 else 2e-2), rel
+    # (5) the graph path reproduces the eager path bit-for-bit, and SGD moves the prompts
+    before = eng.params.clone()
+    loss_graph = tr.forward_backward({"img": img, "label": lab})["loss"]
+    assert loss_graph == l0.item()
+    assert not torch.equal(eng.params, before)

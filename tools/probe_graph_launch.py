@@ -67,3 +67,20 @@ for rep in range(3):
     main.wait_event(ev2); main.wait_event(ev3)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"pipeline emulation: {1e6*(t2-t0):8.1f} us per step")
+
+# --- does a high-priority stream for the image forward remove the text tower's interference? ---
+hi = torch.cuda.Stream(priority=-1)
+lo = torch.cuda.Stream(priority=0)
+for name, s_img, s_txt in (("img hi / text lo", hi, lo), ("img lo / text hi", lo, hi), ("both default", torch.cuda.current_stream(), side)):
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.cuda.stream(s_txt): tr._g_text_fwd.replay()
+        with torch.cuda.stream(s_img): tr._g_img_fwd.replay()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"fwd pair, {name}: {1e6*(t2-t0):8.1f} us")
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.cuda.stream(s_txt): tr._g_text_bwd.replay()
+        with torch.cuda.stream(s_img): tr._g_img_bwd.replay()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"bwd pair, {name}: {1e6*(t2-t0):8.1f} us")
