@@ -113,6 +113,28 @@ def time_dominant_kernel(trainer, batch: int, iters: int = 30):
             "achieved": round(fl / us / 1e6, 1), "unit": "TFLOP/s"}
 
 
+def precision_report(cfg, sd, toks, prompts, dev, batch: int):
+    """bf16 throughput mode vs the f32 parity mode of the SAME kernels on one identical batch: the bf16 error is
+    reported, not assumed (the f32 mode itself is pinned to the reference goldens at <= 1e-3 by tests/)."""
+    from rpo_amd.custom_clip import CustomCLIP
+    img = torch.from_numpy(synth.images(cfg, batch, seed=31)).to(dev)
+    lab = torch.from_numpy(synth.labels(cfg, batch, seed=32)).to(dev)
+    res = {}
+    for name, act in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = CustomCLIP(cfg, sd, toks, dev, act, max_batch=batch, prompts=prompts)
+        m.engine.forward_backward(img, lab)
+        torch.cuda.synchronize()
+        res[name] = (m.engine.logits[:batch].clone(), m.engine.loss.clone(), m.engine.g_text.clone(), m.engine.g_img.clone())
+        del m
+    (lf, sf, tf, gf), (lb, sb, tb, gb) = res["f32"], res["bf16"]
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    return {"reference": "f32 mode of the same kernels (pinned to the reference within 1e-3 by tests/)", "batch": batch,
+            "logits_max_abs_err": round(float((lb - lf).abs().max()), 4), "logits_max_abs": round(float(lf.abs().max()), 3),
+            "loss_abs_err": round(abs(float(sb) - float(sf)), 5),
+            "g_text_rel_err": round(rel(tb, tf), 4), "g_img_rel_err": round(rel(gb, gf), 4),
+            "argmax_agreement": round(float((lb.argmax(-1) == lf.argmax(-1)).float().mean()), 3)}
+
+
 def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
     """CustomCLIP eval branch (trainers/rpo.py:229-232) at the reference's test batch
     (configs/trainers/RPO/main_K24.yaml:5), text features computed once instead of per batch."""
@@ -144,6 +166,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precision", action="store_true", help="skip the bf16-vs-f32 error report")
     ap.add_argument("--eval-batch", type=int, default=0,
                     help="also time the eval branch (logits only, text features cached) at this batch size")
     args = ap.parse_args()
@@ -211,6 +234,10 @@ def main() -> None:
         out["hbm_resident_gb"] = round(tr.engine.hbm_bytes() / 2 ** 30, 2)
         if args.eval_batch > 0:
             out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)
+        if args.dtype == "bf16" and sync.world_size == 1 and not args.no_precision:
+            del tr
+            torch.cuda.empty_cache()
+            out["precision"] = precision_report(cfg, sd, toks, prompts, dev, min(args.batch, 8))
         if sync.world_size == 1 and not args.no_cpu_baseline:
             full = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
             out["cpu_baseline"] = cpu_baseline(cfg, full, toks, prompts)

@@ -6,12 +6,15 @@ export TMPDIR=/tmp
 O=gpurun_out/profiles_raw
 rm -rf $O; mkdir -p $O
 timeout 300 python bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_traced.json 2> $O/trace.err
+timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-precision > $O/bench_traced.json 2> $O/trace.err
 for shape in qkv out_proj c_fc c_proj; do
 for c in "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $c | cut -d" " -f1)
   timeout -k 5 100 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${shape}_$n -o p -- python tools/bench_gemm.py --only $shape > $O/pmc_${shape}_$n.log 2>&1
 done
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_step_$c -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision > $O/pmc_step_$c.log 2>&1
 done
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1

@@ -49,6 +49,27 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         lines.append(f"{'-> HBM traffic (2*FETCH+WRITE)':32s} {(2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) / 1024:.1f} MB\n")
 open(os.path.join(out, f"{tag}_gemm_pmc.txt"), "w").writelines(lines)
+# whole-step HBM traffic: sum of the counter over every kernel between two consecutive sgd launches
+step = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(raw, f"pmc_step_{c}", "**", "*counter_collection.csv"), recursive=True)
+    if not f:
+        continue
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
+    idx = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+    if len(idx) >= 3:
+        seg = rows[idx[-2] + 1: idx[-1] + 1]
+        step[c] = sum(float(r["Counter_Value"]) for r in seg if r["Counter_Name"] == c)
+        step[c + "_n"] = len(seg)
+if step:
+    with open(os.path.join(out, f"{tag}_step_hbm_traffic.txt"), "w") as fo:
+        fo.write("# HBM traffic of ONE train step (all kernels between two sgd launches), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE\n"
+                 "# over `python bench.py --steps 6 --warmup 2` (separate passes).  Units: KB.  FETCH_SIZE under-reports wide\n"
+                 "# coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md), so traffic = 2*FETCH + WRITE.\n")
+        for k, v in step.items():
+            fo.write(f"{k} {v:.6g}\n")
+        if "FETCH_SIZE" in step and "WRITE_SIZE" in step:
+            fo.write(f"traffic_bytes_per_step {(2 * step['FETCH_SIZE'] + step['WRITE_SIZE']) * 1024:.6g}\n")
 for fn in ("gemm_timeline.txt", "graph_phases.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
