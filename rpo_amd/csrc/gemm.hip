@@ -84,7 +84,10 @@ template <> struct Tr<float> {
 //            tile needs 32 KiB per 512 MFMA-cycles = 64 B/clk/CU, which IS the L1/L2->CU rate, so it
 //            cannot pass ~50 % MFMA; 256x256 halves the bytes per flop.
 // (NSTAGE > 2 is supported by the counted-vmcnt loop below, but 3- and 4-stage 128x128 variants at one WG/CU
-//  measured 20-25 % slower than 2 stages at two WG/CU: the loop is bound by in-wave issue, not DMA latency.)
+//  measured 20-25 % slower than 2 stages at two WG/CU: the loop is bound by in-wave issue, not DMA latency.
+//  A persistent variant -- workgroups walking several tiles, next tile's first k-tile fetched under the current
+//  epilogue -- was bit-identical and not faster: with two workgroups per CU the hardware already overlaps one
+//  workgroup's prologue / epilogue with the other's main loop.)
 template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_>
 struct Cfg {
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, NSTAGE = NSTAGE_;

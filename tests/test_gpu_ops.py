@@ -102,6 +102,44 @@ def test_gemm_epilogues(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(3000, 3072, 128), (6400, 1024, 128), (2000, 3072, 64), (7072, 3072, 768)])
+def test_gemm_many_tiles_all_epilogues(mode, M, N, K):
+    """Multi-round launches (more tiles than resident workgroups) of every tile shape the heuristic picks
+    (128x128, 64x128, 64x64), every epilogue, M tail included, against float64; a forced alternative tile
+    shape must give the same bits (the k-order per output element does not depend on the tiling)."""
+    from rpo_amd import _lib as L
+    o = ops()
+    if K == 768 and mode == "f32":
+        pytest.skip("covered by the bf16 run; keeps the CPU reference matmul short")
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias, resid, u = rnd((N,), 3), rnd((M, N), 4), rnd((M, N), 5)
+    acc = q(a, mode) @ q(w, mode).t()
+    ad, wd = a.to(dev(), DT[mode]), w.to(dev(), DT[mode])
+    bd, rd, ud = bias.to(dev()), resid.to(dev()), u.to(dev())
+    row0 = M - 700
+    for epi, kw, ref, odt in (
+            (L.EPI_BIAS, dict(bias=bd), acc + bias.double(), DT[mode]),
+            (L.EPI_BIAS_QGELU, dict(bias=bd, aux_row0=row0), R.qgelu(acc + bias.double()), DT[mode]),
+            (L.EPI_BIAS_RESID, dict(bias=bd, resid=rd), acc + bias.double() + resid.double(), torch.float32),
+            (L.EPI_QGELU_BWD, dict(aux=ud), acc * R.qgelu_grad(u.double()), DT[mode]),
+            (L.EPI_NONE, dict(), acc, torch.float32)):
+        out = torch.full((M, N), float("nan"), dtype=odt, device=dev())
+        if epi == L.EPI_BIAS_QGELU:
+            kw = dict(kw, aux=torch.full((M - row0, N), float("nan"), device=dev()))
+        o.gemm_nt(ad, wd, out, epi, **kw)
+        tol = TOL[mode] if odt != torch.float32 or mode == "f32" else 1e-4
+        close(out, ref, mode, f"gemm epi {epi}", tol=tol)
+        if epi == L.EPI_BIAS_QGELU:
+            close(kw["aux"], (acc + bias.double())[row0:], mode, "gemm saved u", tol=TOL["f32"] if mode == "f32" else 1e-4)
+        out2 = torch.full((M, N), float("nan"), dtype=odt, device=dev())
+        kw2 = dict(kw)
+        if epi == L.EPI_BIAS_QGELU:
+            kw2["aux"] = torch.empty_like(kw["aux"])
+        o.gemm_nt(ad, wd, out2, epi, tile_config=2, **kw2)
+        assert torch.equal(out, out2), "tile shape must not change the result bits"
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_gemm_split_k_feeds_layernorm_bwd(mode):
     """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""
     from rpo_amd import _lib as L
