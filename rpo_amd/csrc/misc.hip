@@ -6,21 +6,28 @@
 namespace {
 
 // ---- im2col for non-overlapping patches (trainers/rpo.py:198-200) -------------------------
+// one thread per 2 consecutive pixels of an image row (8-B fp32 load, packed store); threads of a
+// wave cover consecutive pixels of the image row, so loads coalesce.  Requires patch % 2 == 0.
 template <typename TO>
 __global__ void im2col_kernel(const float* __restrict__ img, TO* out, int64_t ldo, int B, int H, int W,
-                              int p, int total) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (m, c, ky)
+                              int p, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // ((b*3 + c)*H + y) * (W/2) + x2
   if (idx >= total) return;
-  const int g = W / p, gh = H / p;
-  const int ky = idx % p;
-  const int c = (idx / p) % 3;
-  const int m = idx / (3 * p);
-  const int px = m % g, py = (m / g) % gh, b = m / (g * gh);
-  const float* src = img + (((int64_t)b * 3 + c) * H + (py * p + ky)) * W + px * p;
-  TO* dst = out + (int64_t)m * ldo + (c * p + ky) * p;
-  for (int kx = 0; kx < p; ++kx) ActIO<TO>::st(dst + kx, src[kx]);
-  if (c == 2 && ky == p - 1)
-    for (int kx = 3 * p * p; kx < ldo; ++kx) ActIO<TO>::st(out + (int64_t)m * ldo + kx, 0.f);
+  const int w2 = W >> 1;
+  const int x = (int)(idx % w2) * 2;
+  const int64_t row = idx / w2;
+  const int y = (int)(row % H);
+  const int c = (int)((row / H) % 3);
+  const int b = (int)(row / (3 * (int64_t)H));
+  const float2 v = *reinterpret_cast<const float2*>(img + row * W + x);
+  const int g = W / p;
+  const int py = y / p, ky = y - py * p, px = x / p, kx = x - px * p;
+  const int64_t m = ((int64_t)b * (H / p) + py) * g + px;
+  TO* dst = out + m * ldo + (c * p + ky) * p + kx;
+  ActIO<TO>::st(dst, v.x);
+  ActIO<TO>::st(dst + 1, v.y);
+  if (c == 2 && ky == p - 1 && kx + 2 >= p)       // last pixels of the patch: zero the K padding
+    for (int k = 3 * p * p; k < ldo; ++k) ActIO<TO>::st(out + m * ldo + k, 0.f);
 }
 
 __global__ void assemble_kernel(float* x, int64_t ldx, const float* __restrict__ cls,
@@ -230,15 +237,16 @@ extern "C" const char* rpo_error_string(int code) {
 extern "C" int rpo_im2col_patches(const float* img, void* out, int out_dtype, int64_t ldo, int B, int H, int W,
                                   int patch, void* stream) {
   if (!img || !out || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return RPO_E_BADARG;
-  if (H % patch || W % patch || ldo < 3 * patch * patch) return RPO_E_SHAPE;
-  const int m = B * (H / patch) * (W / patch);
-  const int total = m * 3 * patch;
+  if (H % patch || W % patch || patch % 2 || ldo < 3 * patch * patch) return RPO_E_SHAPE;
+  if (reinterpret_cast<uintptr_t>(img) % 8) return RPO_E_ALIGN;
+  const int64_t total = (int64_t)B * 3 * H * (W / 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
   if (out_dtype == RPO_BF16)
-    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, img,
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, img,
                        static_cast<bf16_t*>(out), ldo, B, H, W, patch, total);
   else if (out_dtype == RPO_F32)
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, img,
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, img,
                        static_cast<float*>(out), ldo, B, H, W, patch, total);
   else return RPO_E_DTYPE;
   return rpo_launch_status();
