@@ -78,7 +78,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RPO_HIP_LIB") or LIB_PATH      # RPO_HIP_LIB: A/B a variant build (tools/)
     # PyTorch-ROCm bundles its own libamdhip64.so.7; librpo_hip.so must bind to THAT runtime
     # (same SONAME as /opt/rocm's) or the two would hold separate device contexts and torch's
     # pointers/streams would be foreign to our kernels.  Importing torch first makes the dynamic

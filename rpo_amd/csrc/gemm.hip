@@ -88,9 +88,10 @@ template <> struct Tr<float> {
 //  A persistent variant -- workgroups walking several tiles, next tile's first k-tile fetched under the current
 //  epilogue -- was bit-identical and not faster: with two workgroups per CU the hardware already overlaps one
 //  workgroup's prologue / epilogue with the other's main loop.)
-template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_>
+template <int WAVES_M_, int WAVES_N_, int WM_T_, int WN_T_, int NSTAGE_, int SPREAD_ = 4>
 struct Cfg {
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM_T = WM_T_, WN_T = WN_T_, NSTAGE = NSTAGE_;
+  static constexpr int SPREAD = SPREAD_;
   static constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
   static constexpr int BM = WAVES_M * WM_T * 32, BN = WAVES_N * WN_T * 32;
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -103,10 +104,19 @@ struct Cfg {
   static constexpr int DPT = DA + DW;
   static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split over the waves");
 };
-using CfgMid = Cfg<2, 4, 2, 1, 2>;
-using CfgBig = Cfg<2, 4, 4, 2, 2>;
-using CfgTiny = Cfg<2, 2, 1, 1, 2>;    // 64x64, 4 waves
-using CfgTall = Cfg<2, 4, 1, 1, 2>;    // 64x128, 8 waves
+// SPREAD = k-steps (of 4) over which a k-tile's DMA pieces are issued.  Measured (B=32 shapes, MI355X): the 256x256
+// and 64x64 tiles gain 6-8 % from issuing everything in the first two k-steps (the last two cover the DMA latency
+// before the next vmcnt wait); 128x128 and 64x128 at 2-3 workgroups per CU are best with an even spread.
+#ifndef RPO_SPREAD_MID
+#define RPO_SPREAD_MID 4
+#define RPO_SPREAD_BIG 2
+#define RPO_SPREAD_TINY 2
+#define RPO_SPREAD_TALL 4
+#endif
+using CfgMid = Cfg<2, 4, 2, 1, 2, RPO_SPREAD_MID>;
+using CfgBig = Cfg<2, 4, 4, 2, 2, RPO_SPREAD_BIG>;
+using CfgTiny = Cfg<2, 2, 1, 1, 2, RPO_SPREAD_TINY>;    // 64x64, 4 waves
+using CfgTall = Cfg<2, 4, 1, 1, 2, RPO_SPREAD_TALL>;    // 64x128, 8 waves
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -228,7 +238,9 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     // ~1500 cycles per k-tile for 512 cycles of MFMA).  Interleaved, the issue hides behind running MFMAs.
     const bool more = kt + NSTAGE - 1 < nk;
     const int nstage = (kt + NSTAGE - 1) % NSTAGE, nkt = kt + NSTAGE - 1;
-    constexpr int PPS = (CF::DPT + T::KSTEPS - 1) / T::KSTEPS;   // pieces per k-step
+    // pieces per k-step: spread over the first SPREAD k-steps (bf16: of 4), the rest cover the DMA latency
+    constexpr int SPR = CF::SPREAD < T::KSTEPS ? CF::SPREAD * (T::KSTEPS / 4) : T::KSTEPS;
+    constexpr int PPS = (CF::DPT + SPR - 1) / SPR;
     const char* st = smem + (kt % NSTAGE) * CF::STAGE_BYTES;
     const char* sx = st + rx * LROW;
     const char* sw = st + CF::A_BYTES + rwv * LROW;

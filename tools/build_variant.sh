@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/build_variant.sh NAME [-D...]: builds rpo_amd/build/ab/librpo_NAME.so with extra flags for gemm.hip
+# (other objects reused from the last `python -m rpo_amd.build`); load it with RPO_HIP_LIB=... for A/B runs.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; shift
+mkdir -p $R/rpo_amd/build/ab
+SRC=${SRC:-gemm}
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $R/rpo_amd/csrc/$SRC.hip -o $R/rpo_amd/build/ab/${SRC}_$name.o
+objs=""
+for o in gemm attn_image attn_text norm misc; do
+  if [ $o = $SRC ]; then objs="$objs $R/rpo_amd/build/ab/${SRC}_$name.o"; else objs="$objs $R/rpo_amd/build/$o.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $R/rpo_amd/build/ab/librpo_$name.so
+echo built $name
