@@ -231,6 +231,12 @@ def main() -> None:
     }
     if sync.rank == 0:
         out["roofline"]["dominant_kernel"] = time_dominant_kernel(tr, args.batch)
+        # second denominator: what a pure-MFMA loop / a stream copy sustain on THIS box
+        from rpo_amd import ops as _ops
+        pk = _ops.probe_peaks(dev, 0 if args.dtype == "bf16" else 1)
+        out["roofline"]["empirical"] = {"mfma_tflops": round(pk["mfma_tflops"], 1),
+                                        "copy_gbs": round(pk["copy_gbs"], 1),
+                                        "frac_of_empirical_mfma": round(achieved / pk["mfma_tflops"], 4)}
         out["hbm_resident_gb"] = round(tr.engine.hbm_bytes() / 2 ** 30, 2)
         if args.eval_batch > 0:
             out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)

@@ -188,6 +188,13 @@ int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dtype, int64_t
  * d [32,32] fp32 receives D[i][j] = sum_k a[i][k] * b[j][k] as the kernels' layout map decodes it. */
 int rpo_probe_mfma(int which, const float* a, const float* b, float* d, void* stream);
 
+/* Empirical peaks of the box, used as second denominators by bench.py.
+ * rpo_probe_peak_mfma: `blocks` workgroups of 4 waves each run `iters` rounds of 4 independent 32x32 MFMAs
+ * (which: 0 = 32x32x16 bf16, 1 = 32x32x2 f32) on non-zero operands; *flops receives the flop count of the
+ * launch (time it with events).  rpo_probe_peak_copy: 16-B-per-lane grid-stride copy of `bytes` bytes. */
+int rpo_probe_peak_mfma(int which, int blocks, int iters, float* sink, double* flops, void* stream);
+int rpo_probe_peak_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

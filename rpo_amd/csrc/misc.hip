@@ -195,6 +195,45 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // ---- MFMA layout probe ------------------------------------------------------------------------
+// ---- empirical peaks ("measure empirical peaks on the box ... and use those as denominators too") ----
+// pure-MFMA loop: every wave keeps 4 independent 32x32 accumulators busy, nothing else.  which: 0 bf16, 1 f32.
+template <int WHICH>
+__global__ __launch_bounds__(256) void peak_mfma_kernel(float* sink, int iters) {
+  f32x16_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // random-looking, non-zero operands: zero-filled operands run faster than real data on this chip
+  const float seed = 0.001f * (float)((threadIdx.x * 37 + blockIdx.x * 11) % 251) - 0.125f;
+  if constexpr (WHICH == 0) {
+    bf16x8_t a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + 0.01f * i); b[i] = (__bf16)(0.5f - seed * (i + 1)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    }
+  } else {
+    float a = seed, b = 0.5f - seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[t][r];
+  if (s == 12345.678f) sink[0] = s;           // keeps the loop alive; practically never true
+}
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const uint4* __restrict__ src, uint4* dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 __global__ void probe_kernel(int which, const float* a, const float* b, float* d) {
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
   f32x16_t acc;
@@ -335,5 +374,23 @@ extern "C" int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dty
 extern "C" int rpo_probe_mfma(int which, const float* a, const float* b, float* d, void* stream) {
   if (!a || !b || !d || (which != 0 && which != 1)) return RPO_E_BADARG;
   hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), which, a, b, d);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_probe_peak_mfma(int which, int blocks, int iters, float* sink, double* flops, void* stream) {
+  if (!sink || !flops || blocks <= 0 || iters <= 0 || (which != 0 && which != 1)) return RPO_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (which == 0) hipLaunchKernelGGL(peak_mfma_kernel<0>, dim3(blocks), dim3(256), 0, s, sink, iters);
+  else hipLaunchKernelGGL(peak_mfma_kernel<1>, dim3(blocks), dim3(256), 0, s, sink, iters);
+  const double per_mfma = which == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;
+  *flops = per_mfma * 4.0 * (double)iters * 4.0 * (double)blocks;   // 4 accumulators, 4 waves per block
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_probe_peak_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes <= 0 || bytes % 16) return RPO_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(src) % 16 || reinterpret_cast<uintptr_t>(dst) % 16) return RPO_E_ALIGN;
+  hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
   return rpo_launch_status();
 }

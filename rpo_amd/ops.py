@@ -194,3 +194,35 @@ def probe_mfma(which: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     check(_lib.load().rpo_probe_mfma(which, a.data_ptr(), b.data_ptr(), d.data_ptr(), _stream()),
           "rpo_probe_mfma")
     return d
+
+
+def probe_peaks(device: torch.device, which: int = 0) -> dict:
+    """Empirical peaks of this GPU: sustained MFMA TFLOP/s of a pure-MFMA loop (8 waves per SIMD-pair resident,
+    non-zero operands) and GB/s of a 1 GiB stream copy (read + write bytes).  ~0.2 s."""
+    import ctypes
+    lib = _lib.load()
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    flops = ctypes.c_double(0.0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    blocks, iters = 256 * 8, 4096 if which == 0 else 2048
+    for timed in (False, True):
+        if timed:
+            ev[0].record()
+        check(lib.rpo_probe_peak_mfma(which, blocks, iters, sink.data_ptr(), ctypes.byref(flops), _stream()),
+              "rpo_probe_peak_mfma")
+        if timed:
+            ev[1].record()
+    n = 1 << 29
+    src = torch.empty(n, dtype=torch.uint8, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    reps = 5
+    for timed in (False, True):
+        if timed:
+            ev[2].record()
+        for _ in range(reps if timed else 1):
+            check(lib.rpo_probe_peak_copy(src.data_ptr(), dst.data_ptr(), n, _stream()), "rpo_probe_peak_copy")
+        if timed:
+            ev[3].record()
+    torch.cuda.synchronize(device)
+    return {"mfma_tflops": flops.value / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12,
+            "copy_gbs": 2.0 * n * reps / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9}

@@ -350,3 +350,15 @@ def test_argument_errors_are_reported():
     with pytest.raises(RPOLibraryError):
         o.layernorm_fwd(torch.zeros(4, 30, device=dev()), torch.zeros(30, device=dev()),
                         torch.zeros(30, device=dev()), torch.zeros(4, 30, device=dev()))
+
+
+@pytest.mark.gpu
+def test_peak_probes_are_sane():
+    """The empirical-peak probes bench.py uses as second roofline denominators: above what our own GEMM
+    reaches, below the datasheet peaks (2.5 PFLOP/s bf16, 157 TFLOP/s f32, 8 TB/s)."""
+    o = ops()
+    bf = o.probe_peaks(dev(), 0)
+    assert 800.0 < bf["mfma_tflops"] < 2600.0, bf
+    assert 1500.0 < bf["copy_gbs"] < 8100.0, bf
+    f32 = o.probe_peaks(dev(), 1)
+    assert 80.0 < f32["mfma_tflops"] < 165.0, f32
