@@ -34,6 +34,7 @@
 #ifndef RPO_AMD_H
 #define RPO_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -48,7 +49,8 @@ enum {
   RPO_E_BADARG = -1,   /* null pointer / non-positive size */
   RPO_E_SHAPE = -2,    /* size not supported by the kernels (see each function) */
   RPO_E_DTYPE = -3,    /* dtype combination not supported */
-  RPO_E_ALIGN = -4     /* pointer / leading dimension not 16-byte aligned */
+  RPO_E_ALIGN = -4,    /* pointer / leading dimension not 16-byte aligned */
+  RPO_E_WORKSPACE = -5 /* caller-provided workspace / table bounds too small for this call */
 };
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */
@@ -187,6 +189,38 @@ int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dtype, int64_t
  * 1 = 32x32x2 f32.  a [32, kdim], b [32, kdim] fp32 host-layout inputs (device memory),
  * d [32,32] fp32 receives D[i][j] = sum_k a[i][k] * b[j][k] as the kernels' layout map decodes it. */
 int rpo_probe_mfma(int which, const float* a, const float* b, float* d, void* stream);
+
+/* ---- on-device input transforms -------------------------------------------------------
+ * Replaces, for a batch of decoded uint8 RGB images of arbitrary sizes, the reference's per-sample CPU transforms
+ * selected by configs/trainers/RPO/main_K24.yaml:8-13 (INTERPOLATION bicubic, PIXEL_MEAN/STD, TRANSFORMS
+ * random_resized_crop + random_flip + normalize; test: resize + center crop + normalize), whose arithmetic is
+ * Pillow's 8-bit bicubic resample reached through Dassl -> torchvision (both un-vendored).  Output is
+ * BIT-IDENTICAL to PIL crop -> resize(BICUBIC) -> [crop window] -> [flip] -> ToTensor -> Normalize.
+ *
+ * One image = crop box (PIL crop), size the crop is resized to, window of the resized image that becomes the
+ * size x size output (win = 0,0 and resize = size for the train transform; the center-crop offsets at test time),
+ * and a flip flag.  All random decisions are made by the caller (rpo_amd/input_pipeline.py). */
+typedef struct rpo_image_desc {
+  int64_t src_offset;                      /* byte offset of the image in `src` (HWC uint8 RGB, rows packed) */
+  int32_t width, height;                   /* source image size */
+  int32_t crop_x, crop_y, crop_w, crop_h;  /* crop box, inside the image */
+  int32_t resize_w, resize_h;              /* size the crop is resized to (>= size) */
+  int32_t win_x, win_y;                    /* window origin in the resized image */
+  int32_t flip;                            /* horizontal flip of the output */
+  int32_t reserved;
+} rpo_image_desc;
+
+/* number of taps Pillow uses for in_size -> out_size (1 when the pass is skipped); kmax of a batch = max of these */
+int rpo_preprocess_ksize(int in_size, int out_size);
+/* bytes of caller-owned workspace for B images, output size `size`, crops of at most max_rows rows, kmax taps */
+size_t rpo_preprocess_workspace_bytes(int B, int size, int max_rows, int kmax);
+/* src: device buffer holding the B images; desc_host/desc_dev: the same B descriptors in host and device memory
+ * (the host copy is validated -> RPO_E_SHAPE / RPO_E_WORKSPACE, the device copy is what the kernels read);
+ * mean3/std3: host pointers; out: fp32 [B, 3, size, size] device.  Enqueues three kernels on `stream`. */
+int rpo_preprocess_batch(const uint8_t* src, int64_t src_bytes, const rpo_image_desc* desc_host,
+                         const rpo_image_desc* desc_dev, int B, int size, int max_rows, int kmax,
+                         const float* mean3, const float* std3, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* Empirical peaks of the box, used as second denominators by bench.py.
  * rpo_probe_peak_mfma: `blocks` workgroups of 4 waves each run `iters` rounds of 4 independent 32x32 MFMAs

@@ -18,6 +18,14 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH = r
 c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
 
+class ImageDesc(C.Structure):
+    """struct rpo_image_desc (include/rpo_amd.h)."""
+    _fields_ = [("src_offset", c_i64), ("width", c_i32), ("height", c_i32),
+                ("crop_x", c_i32), ("crop_y", c_i32), ("crop_w", c_i32), ("crop_h", c_i32),
+                ("resize_w", c_i32), ("resize_h", c_i32), ("win_x", c_i32), ("win_y", c_i32),
+                ("flip", c_i32), ("reserved", c_i32)]
+
+
 class GemmArgs(C.Structure):
     """struct rpo_gemm_args (include/rpo_amd.h)."""
     _fields_ = [
@@ -66,6 +74,10 @@ SIGNATURES = {
     "rpo_probe_mfma": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rpo_probe_peak_mfma": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rpo_probe_peak_copy": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rpo_preprocess_ksize": (c_i32, [c_i32, c_i32]),
+    "rpo_preprocess_workspace_bytes": (C.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
+    "rpo_preprocess_batch": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                     C.c_size_t, c_vp]),
 }
 
 _lib = None

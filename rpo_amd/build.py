@@ -10,7 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpo_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip"]
+# preprocess.hip reproduces Pillow's double-precision coefficient math bit for bit: no FMA contraction
+EXTRA_FLAGS = {"preprocess.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -39,7 +41,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -269,6 +269,7 @@ extern "C" const char* rpo_error_string(int code) {
     case RPO_E_SHAPE: return "rpo: shape not supported by the kernel";
     case RPO_E_DTYPE: return "rpo: dtype combination not supported";
     case RPO_E_ALIGN: return "rpo: pointer or leading dimension not sufficiently aligned";
+    case RPO_E_WORKSPACE: return "rpo: workspace or table bound too small for this call";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rpo: unknown error";
   }
 }

@@ -94,3 +94,62 @@ def test_config_dims():
     b, l = vit_b16(), vit_l14()
     assert (b.n_frozen, b.seq_v, b.heads_v, b.heads_t, b.patch_dim) == (197, 221, 12, 8, 768)
     assert (l.n_frozen, l.seq_v, l.heads_v, l.heads_t, l.patch_dim) == (257, 281, 16, 12, 588)
+
+
+# ---- input pipeline host logic (rpo_amd/input_pipeline.py) ------------------------------------------------------
+
+def test_input_pipeline_plans_match_oracle_sampler():
+    from oracle import resample_oracle as R
+    from rpo_amd import input_pipeline as ip
+
+    class Seq:
+        def __init__(self, seed): self.g = np.random.default_rng(seed)
+        def uniform(self, a, b): return a + (b - a) * float(self.g.random())
+        def randint(self, lo, hi): return int(self.g.integers(lo, hi))
+        def rand(self): return float(self.g.random())
+    for seed, (h, w) in enumerate([(375, 500), (500, 375), (40, 2000), (2000, 40), (224, 224), (1, 1)]):
+        assert ip.random_resized_crop_params(h, w, Seq(seed)) == R.random_resized_crop_params(h, w, Seq(seed))
+        assert ip.center_crop_window(h, w, 224) == R.eval_window(h, w, 224)
+    assert ip.CLIP_MEAN == R.CLIP_MEAN and ip.CLIP_STD == R.CLIP_STD
+
+
+def test_torch_rng_crops_are_reproducible_and_inside_the_image():
+    import torch
+    from rpo_amd import input_pipeline as ip
+    torch.manual_seed(123)
+    a = [ip.random_resized_crop_params(375, 500, ip.TorchRng()) for _ in range(50)]
+    torch.manual_seed(123)
+    b = [ip.random_resized_crop_params(375, 500, ip.TorchRng()) for _ in range(50)]
+    assert a == b and len(set(a)) > 40
+    for i, j, h, w in a:
+        assert 0 <= i and i + h <= 375 and 0 <= j and j + w <= 500 and h > 0 and w > 0
+        assert 0.08 * 375 * 500 * 0.9 <= h * w <= 375 * 500
+
+
+def test_subsample_classes_and_fewshot():
+    """datasets/oxford_pets.py:140-186 (base = first ceil(n/2) labels, relabelled from 0) and the Dassl few-shot
+    sampler it calls at :44-45."""
+    import random
+    from rpo_amd.input_pipeline import Datum, generate_fewshot_dataset, subsample_classes
+    data = [Datum(f"img_{c}_{k}.jpg", c, f"class{c}") for c in range(37) for k in range(6)]
+    test = [Datum(f"t_{c}.jpg", c, f"class{c}") for c in range(37)]
+    base_tr, base_te = subsample_classes(data, test, subsample="base")
+    new_tr, new_te = subsample_classes(data, test, subsample="new")
+    assert sorted({d.label for d in base_tr}) == list(range(19)) and len(base_te) == 19
+    assert sorted({d.label for d in new_tr}) == list(range(18)) and len(new_te) == 18
+    assert {d.classname for d in new_tr} == {f"class{c}" for c in range(19, 37)}
+    assert new_te[0].classname == "class19" and new_te[0].label == 0
+    allx, = subsample_classes(data, subsample="all")
+    assert len(allx) == len(data)
+    shots = generate_fewshot_dataset(base_tr, 4, rng=random.Random(1))
+    assert len(shots) == 19 * 4
+    per = {}
+    for d in shots:
+        per.setdefault(d.label, set()).add(d.impath)
+    assert all(len(v) == 4 for v in per.values())
+    again = generate_fewshot_dataset(base_tr, 4, rng=random.Random(1))
+    assert [d.impath for d in again] == [d.impath for d in shots]
+    few = generate_fewshot_dataset(base_tr[:3], 16)                       # fewer than num_shots: keep all
+    assert len(few) == 3
+    rep = generate_fewshot_dataset(base_tr[:3], 16, repeat=True, rng=random.Random(0))
+    assert len(rep) == 16
