@@ -155,6 +155,70 @@ def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
             "note": "eager launches (no graph); text tower skipped after the first batch"}
 
 
+def time_input_pipeline(dev, batch: int, iters: int = 20):
+    """the train transform (random_resized_crop + flip + normalize) of `batch` decoded
+    375x500 uint8 images per call, host packing + H2D + kernels (`with_h2d`) and kernels alone on a resident
+    batch (`device_only`, HIP events); next to it Pillow on ONE host core for the same plans (bounded sample)."""
+    from rpo_amd.input_pipeline import InputConfig, build_transform
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (375, 500, 3), dtype=np.uint8) for _ in range(batch)]
+    tf = build_transform(InputConfig(), True, dev, batch)
+    torch.manual_seed(0)
+    plans = [tf.plan(375, 500) for _ in imgs]
+    out = torch.empty(batch, 3, 224, 224, device=dev)
+    for _ in range(3):
+        tf(imgs, plans, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tf(imgs, plans, out)
+    torch.cuda.synchronize()
+    with_h2d = batch * iters / (time.perf_counter() - t0)
+    # kernels alone: replay the last call's device-side state
+    import ctypes
+    from rpo_amd import _lib as L
+    slot = tf.slots[tf.turn ^ 1]
+    lib = L.load()
+    descs = (L.ImageDesc * batch).from_buffer_copy(bytes(slot["host"][:ctypes.sizeof(L.ImageDesc) * batch].numpy()))
+    max_rows = max(d.crop_h for d in descs)
+    kmax = max(max(lib.rpo_preprocess_ksize(d.crop_w, d.resize_w), lib.rpo_preprocess_ksize(d.crop_h, d.resize_h))
+               for d in descs)
+    nbytes = max(d.src_offset + d.width * d.height * 3 for d in descs)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    def run():
+        rc = lib.rpo_preprocess_batch(slot["dev"].data_ptr() + tf.desc_bytes, nbytes, ctypes.addressof(descs),
+                                      slot["dev"].data_ptr(), batch, 224, max_rows, kmax, ctypes.addressof(tf.mean),
+                                      ctypes.addressof(tf.std), out.data_ptr(), slot["ws"].data_ptr(),
+                                      slot["ws"].numel(), st)
+        assert rc == 0, rc
+    run()
+    s.record()
+    for _ in range(iters):
+        run()
+    e.record(); e.synchronize()
+    dev_only = batch * iters / (s.elapsed_time(e) * 1e-3)
+    res = {"workload": f"{batch} x 375x500x3 uint8 -> random_resized_crop+flip+normalize -> [{batch},3,224,224] f32",
+           "images_per_s_with_h2d": round(with_h2d, 1), "images_per_s_device_only": round(dev_only, 1),
+           "src_bytes_per_image": 375 * 500 * 3}
+    try:
+        from PIL import Image
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            im, pl = imgs[n % batch], plans[n % batch]
+            top, left, h, w = pl.crop
+            o = Image.fromarray(im).crop((left, top, left + w, top + h)).resize((224, 224), Image.BICUBIC)
+            if pl.flip:
+                o = o.transpose(Image.FLIP_LEFT_RIGHT)
+            t = torch.from_numpy(np.asarray(o).copy()).permute(2, 0, 1).float().div(255)
+            n += 1
+        res["pillow_images_per_s_one_core"] = round(n / (time.perf_counter() - t0), 1)
+    except ImportError:
+        pass
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +231,7 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision", action="store_true", help="skip the bf16-vs-f32 error report")
+    ap.add_argument("--input-pipeline", action="store_true", help="also time the on-device input transforms")
     ap.add_argument("--eval-batch", type=int, default=0,
                     help="also time the eval branch (logits only, text features cached) at this batch size")
     args = ap.parse_args()
@@ -238,6 +303,8 @@ def main() -> None:
                                         "copy_gbs": round(pk["copy_gbs"], 1),
                                         "frac_of_empirical_mfma": round(achieved / pk["mfma_tflops"], 4)}
         out["hbm_resident_gb"] = round(tr.engine.hbm_bytes() / 2 ** 30, 2)
+        if args.input_pipeline:
+            out["input_pipeline"] = time_input_pipeline(dev, args.batch)
         if args.eval_batch > 0:
             out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)
         if args.dtype == "bf16" and sync.world_size == 1 and not args.no_precision:

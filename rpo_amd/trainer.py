@@ -78,10 +78,26 @@ class RPO:
         if self.sync.enabled:                       # identical prompts on every rank
             self.sync.broadcast(self.engine.params)
 
+    def transform(self, is_train: bool):
+        """Device-side counterpart of Dassl's `build_transform(cfg, is_train)` (rpo_amd/input_pipeline.py),
+        built on first use."""
+        from .input_pipeline import InputConfig, build_transform
+        key = "_tf_train" if is_train else "_tf_test"
+        if getattr(self, key, None) is None:
+            icfg = InputConfig(SIZE=(self.cfg.image_size, self.cfg.image_size))
+            setattr(self, key, build_transform(icfg, is_train, self.device, self.batch_size))
+        return getattr(self, key)
+
     def parse_batch_train(self, batch):
-        """trainers/rpo.py:318-323."""
-        return (batch["img"].to(self.device, dtype=torch.float32, non_blocking=True),
-                batch["label"].to(self.device, dtype=torch.int64, non_blocking=True))
+        """trainers/rpo.py:318-323.  `batch["img"]` is either the float tensor the reference's DataLoader yields
+        (transforms already applied) or a list of decoded uint8 [H, W, 3] images, in which case
+        random_resized_crop + random_flip + normalize run on the device straight into the step's input buffer."""
+        img = batch["img"]
+        if isinstance(img, (list, tuple)):
+            img = self.transform(True)(img, out=self._image if len(img) == self.batch_size else None)
+        else:
+            img = img.to(self.device, dtype=torch.float32, non_blocking=True)
+        return img, torch.as_tensor(batch["label"]).to(self.device, dtype=torch.int64, non_blocking=True)
 
     def _capture(self) -> None:
         """Capture the step as FIVE HIP graphs on two streams instead of one graph with parallel
@@ -144,7 +160,8 @@ class RPO:
         """One optimisation step, nothing synchronised; returns the device loss scalar."""
         eng, oc = self.engine, self.optim_cfg
         assert image.shape[0] == self.batch_size, "graph path needs the configured batch size"
-        self._image.copy_(image, non_blocking=True)
+        if image.data_ptr() != self._image.data_ptr():
+            self._image.copy_(image, non_blocking=True)
         self._label.copy_(label, non_blocking=True)
         if self.use_graph:
             if self._graph is None:
@@ -166,7 +183,9 @@ class RPO:
 
     # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
     @torch.no_grad()
-    def model_inference(self, image: torch.Tensor) -> torch.Tensor:
+    def model_inference(self, image) -> torch.Tensor:
+        if isinstance(image, (list, tuple)):                    # decoded uint8 images: resize + center crop + normalize
+            image = self.transform(False)(image)
         self.model.prompt_learner.eval()
         try:
             return self.model(image)

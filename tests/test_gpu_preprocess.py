@@ -115,3 +115,35 @@ def test_bad_descriptors_fail_loudly():
         tf([img.astype(np.float32)])
     out = tf([img], [SamplePlan((0, 0, 100, 100), (224, 224), (0, 0), False)])    # still usable afterwards
     assert torch.isfinite(out).all()
+
+
+def test_trainer_consumes_decoded_images():
+    """RPO.forward_backward / model_inference fed with decoded uint8 images (device transforms) == the same trainer
+    fed with the float tensors the Pillow-pinned oracle produces for the same plans."""
+    from helpers import workload
+    from rpo_amd.trainer import RPO
+    cfg, sd, toks, tp, ip, _, _ = workload("d1_k4_b2")
+    prompts = (tp, ip)
+    rng = np.random.default_rng(12)
+    B = 4
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in [(300, 400), (256, 256), (500, 333), (224, 224)]]
+    labels = np.array([1, 0, 3, 2])
+    losses = []
+    for mode in ("uint8", "float"):
+        tr = RPO(cfg, sd, toks, device="cuda:0", act_dtype=torch.float32, batch_size=B, prompts=prompts)
+        torch.manual_seed(77)
+        if mode == "uint8":
+            out = tr.forward_backward({"img": imgs, "label": labels})
+        else:
+            tf = tr.transform(True)
+            plans = [tf.plan(im.shape[0], im.shape[1]) for im in imgs]
+            x = np.stack([oracle_plan(im, pl, 224) for im, pl in zip(imgs, plans)])
+            out = tr.forward_backward({"img": torch.from_numpy(x), "label": torch.from_numpy(labels)})
+        losses.append((out["loss"], tr.engine.params.clone()))
+        if mode == "uint8":
+            ev = tr.model_inference(imgs).cpu().numpy()
+        else:
+            xe = torch.from_numpy(np.stack([R.eval_transform(im) for im in imgs]))
+            assert np.array_equal(ev, tr.model_inference(xe.cuda()).cpu().numpy())
+    assert losses[0][0] == losses[1][0]
+    assert torch.equal(losses[0][1], losses[1][1])
