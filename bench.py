@@ -219,6 +219,23 @@ def time_input_pipeline(dev, batch: int, iters: int = 20):
     return res
 
 
+def committed_step_traffic(args):
+    """HBM bytes per step from the committed rocprofv3 PMC summary (profiles/rNN_step_hbm_traffic.txt: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, 2*FETCH + WRITE per MI355X_MICROARCH.md).  bench.py
+    cannot collect counters itself, so the number is only attached for the workload it was measured on."""
+    if (args.model, args.K, args.batch, args.dtype, args.no_graph) != ("ViT-B/16", 24, 32, "bf16", False):
+        return None, None
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_step_hbm_traffic.txt")))
+    if not files:
+        return None, None
+    for line in open(files[-1]):
+        if line.startswith("traffic_bytes_per_step"):
+            return float(line.split()[1]), os.path.relpath(files[-1], here)
+    return None, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +295,7 @@ def main() -> None:
     fl_step = flops_step(cfg, args.batch, lens)          # per GPU (text tower recomputed on every rank)
     achieved = fl_step / (dt / args.steps) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
+    traffic, traffic_src = committed_step_traffic(args)
     out = {
         "metric": "images/sec (train step, ViT-B/16 K=24)" if (args.model, args.K) == ("ViT-B/16", 24)
         else f"images/sec (train step, {args.model} K={args.K})",
@@ -289,7 +307,8 @@ def main() -> None:
                    "global_batch": global_batch, "parallelism": f"dp{sync.world_size}",
                    "hip_graph": not args.no_graph, "final_loss": round(last_loss, 5)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/step/GPU",
+                     "traffic_source": traffic_src,
                      "algorithmic_gflop_per_step_per_gpu": round(fl_step / 1e9, 2),
                      "gflop_per_image": round(sum(flops_image(cfg)) / 1e9, 2),
                      "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2)},

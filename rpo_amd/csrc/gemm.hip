@@ -122,6 +122,158 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Workgroup id -> tile origin.  XCD-aware bijective remap (guide T1): XCD x = bid % 8 gets a contiguous run of
+// tiles; grouped order: consecutive ids sweep GM m-tiles of one n-tile, then the next n-tile, so the workgroups
+// resident on one XCD form a compact super-tile whose A and W panels fit its 4 MiB L2.
+template <int BM, int BN>
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  }
+  constexpr int GM = 8;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group;
+  const int gm = min(GM, tiles_m - grp * GM);
+  const int in_grp = wg - grp * per_group;
+  const int tile_m = grp * GM + in_grp % gm, tile_n = in_grp / gm;
+  m0 = tile_m * BM; n0 = tile_n * BN;
+}
+
+template <typename TOut, int EPI, typename CF>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[CF::WN_T][CF::WM_T], char* smem,
+                                              const int m0, const int n0) {
+  constexpr int BM = CF::BM, BN = CF::BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / CF::WAVES_N, wn = wave % CF::WAVES_N;
+  // ---- epilogue, staged through LDS -------------------------------------------------------------
+  // acc[tn][tm] holds D[n][m] (lane: m = l31, n = 8*g + 4*half + j, reg = 4*g + j).  Storing straight from
+  // that layout means 8-B pieces scattered over 32 rows per instruction; measured with s_memtime it cost
+  // 9-24 k cycles per workgroup (25-33 % of its lifetime; the store tail is issue-bound, guide T21).  So the
+  // tile is first written to LDS (free after the last k-tile), then walked row-major: every global load
+  // (residual, saved pre-activation) and store is a fully coalesced 16-B-per-lane access.
+  //   PRECONV (256x256, bf16 out, bias only): bias added in the fragment layout, tile staged as bf16
+  //   otherwise: tile staged as fp32, bias / residual / QuickGELU applied in the row-major pass
+  constexpr bool PRECONV = CF::PRECONV_EPI;
+  constexpr int CROW = CF::CROW_BYTES(PRECONV);
+  constexpr bool HAS_BIAS = EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID;
+  __builtin_amdgcn_s_barrier();              // everybody is done reading the last stage
+  if constexpr (PRECONV) {
+    const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
+    float4 bias_r[CF::WN_T][4];
+#pragma unroll
+    for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias_r[tn][g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tm = 0; tm < CF::WM_T; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
+          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
+          const float4 b4 = bias_r[tn][g];
+          float4 v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
+                                 acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
+          if (EPI == RPO_EPI_BIAS_QGELU) {
+            const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
+            if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
+              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+          }
+          *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
+              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                       // 16-B chunks per row
+    constexpr int RPP = CF::THREADS / CPR;            // rows per pass
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 8;
+#pragma unroll 4
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      const int row = pass * RPP + r0;
+      const int m = m0 + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
+    }
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < CF::WM_T; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
+          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
+          *reinterpret_cast<float4*>(smem + row * CROW + col * 4) =
+              make_float4(acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]);
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 4;                       // float4 chunks per row
+    constexpr int RPP = CF::THREADS / CPR;
+    constexpr int UNR = 4;                            // rows whose loads are issued together
+    const int cc = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + cc * 4;
+    const bool nok = n < p.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
+    for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
+      float4 ex[UNR];
+      int64_t orow[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int m = m0 + (pass0 + u) * RPP + r0;
+        ok[u] = nok && m < p.M;
+        const int mc = min(m, p.M - 1);
+        orow[u] = mc;
+        ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == RPO_EPI_PATCH) {
+          const int img = mc / p.group;
+          orow[u] = (int64_t)mc + img + 1;
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
+        } else if (EPI == RPO_EPI_BIAS_RESID) {
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
+        } else if (EPI == RPO_EPI_QGELU_BWD) {
+          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int row = (pass0 + u) * RPP + r0;
+        const int m = m0 + row;
+        float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (EPI == RPO_EPI_BIAS_QGELU) {
+          if (ok[u] && p.aux != nullptr && m >= p.aux_row0)
+            *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+          v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+        }
+        if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
+          v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
+        }
+        if (EPI == RPO_EPI_QGELU_BWD) {
+          v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
+          v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
+        }
+        if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+}
+
 template <typename TIn, typename TOut, int EPI, typename CF>
 __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,24 +286,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   const int wm = wave / CF::WAVES_N, wn = wave % CF::WAVES_N;
 
   RPO_STAMP(0);
-  const int tiles_n = (p.N + BN - 1) / BN;
-  // XCD-aware bijective remap (guide T1): XCD x = bid % 8 gets a contiguous run of tiles
-  int wg;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  }
-  // grouped order: consecutive ids sweep GM m-tiles of one n-tile, then the next n-tile, so the
-  // workgroups resident on one XCD form a compact super-tile whose A and W panels fit its 4 MiB L2
-  constexpr int GM = 8;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int per_group = GM * tiles_n;
-  const int grp = wg / per_group;
-  const int gm = min(GM, tiles_m - grp * GM);
-  const int in_grp = wg - grp * per_group;
-  const int tile_m = grp * GM + in_grp % gm, tile_n = in_grp / gm;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int m0, n0;
+  tile_origin<BM, BN>(p, m0, n0);
   if (p.skip_row0 >= 0 && m0 >= p.skip_row0 && n0 >= p.skip_col0) return;
 
   // k-range of this split
@@ -281,129 +417,222 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 
 
   RPO_STAMP(60);
-  // ---- epilogue, staged through LDS -------------------------------------------------------------
-  // acc[tn][tm] holds D[n][m] (lane: m = l31, n = 8*g + 4*half + j, reg = 4*g + j).  Storing straight from
-  // that layout means 8-B pieces scattered over 32 rows per instruction; measured with s_memtime it cost
-  // 9-24 k cycles per workgroup (25-33 % of its lifetime; the store tail is issue-bound, guide T21).  So the
-  // tile is first written to LDS (free after the last k-tile), then walked row-major: every global load
-  // (residual, saved pre-activation) and store is a fully coalesced 16-B-per-lane access.
-  //   PRECONV (256x256, bf16 out, bias only): bias added in the fragment layout, tile staged as bf16
-  //   otherwise: tile staged as fp32, bias / residual / QuickGELU applied in the row-major pass
-  constexpr bool PRECONV = CF::PRECONV_EPI;
-  constexpr int CROW = CF::CROW_BYTES(PRECONV);
-  constexpr bool HAS_BIAS = EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID;
-  __builtin_amdgcn_s_barrier();              // everybody is done reading the last stage
-  if constexpr (PRECONV) {
-    const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
-    float4 bias_r[CF::WN_T][4];
-#pragma unroll
-    for (int tn = 0; tn < CF::WN_T; ++tn)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bias_r[tn][g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int tm = 0; tm < CF::WM_T; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < CF::WN_T; ++tn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
-          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
-          const float4 b4 = bias_r[tn][g];
-          float4 v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
-                                 acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
-          if (EPI == RPO_EPI_BIAS_QGELU) {
-            const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
-            if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
-              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
-            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-          }
-          *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
-              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-        }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                       // 16-B chunks per row
-    constexpr int RPP = CF::THREADS / CPR;            // rows per pass
-    const int cc = tid % CPR, r0 = tid / CPR;
-    const int n = n0 + cc * 8;
-#pragma unroll 4
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-      const int row = pass * RPP + r0;
-      const int m = m0 + row;
-      const uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
-      if (m < p.M && n < p.N)
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
-    }
-  } else {
-#pragma unroll
-    for (int tm = 0; tm < CF::WM_T; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < CF::WN_T; ++tn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
-          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
-          *reinterpret_cast<float4*>(smem + row * CROW + col * 4) =
-              make_float4(acc[tn][tm][4 * g], acc[tn][tm][4 * g + 1], acc[tn][tm][4 * g + 2], acc[tn][tm][4 * g + 3]);
-        }
-    __syncthreads();
-    constexpr int CPR = BN / 4;                       // float4 chunks per row
-    constexpr int RPP = CF::THREADS / CPR;
-    constexpr int UNR = 4;                            // rows whose loads are issued together
-    const int cc = tid % CPR, r0 = tid / CPR;
-    const int n = n0 + cc * 4;
-    const bool nok = n < p.N;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
-    TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
-    for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
-      float4 ex[UNR];
-      int64_t orow[UNR];
-      bool ok[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int m = m0 + (pass0 + u) * RPP + r0;
-        ok[u] = nok && m < p.M;
-        const int mc = min(m, p.M - 1);
-        orow[u] = mc;
-        ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == RPO_EPI_PATCH) {
-          const int img = mc / p.group;
-          orow[u] = (int64_t)mc + img + 1;
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
-        } else if (EPI == RPO_EPI_BIAS_RESID) {
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
-        } else if (EPI == RPO_EPI_QGELU_BWD) {
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int row = (pass0 + u) * RPP + r0;
-        const int m = m0 + row;
-        float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        if (EPI == RPO_EPI_BIAS_QGELU) {
-          if (ok[u] && p.aux != nullptr && m >= p.aux_row0)
-            *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
-          v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-        }
-        if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
-          v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
-        }
-        if (EPI == RPO_EPI_QGELU_BWD) {
-          v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
-          v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
-        }
-        if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
-      }
-    }
-  }
+  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0);
 #ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RPO_STAMP(61);
+}
+
+// ---- ping-pong 256x256 kernel (bf16) ---------------------------------------------------------------------
+// The lock-step loop above leaves the matrix pipe idle whenever a wave reads fragments, issues DMA or waits at the
+// barrier, and both waves of a SIMD do that at the same time (s_memtime: ~3.6 k cycles per 64-deep k-tile for 2.05 k
+// cycles of MFMA).  Here the 8 waves form two groups (wm = 0 / 1: the two 128-row halves of the tile), one wave of
+// each group per SIMD, and time is cut into slots by raw barriers: in every slot ONE group issues nothing but the 16
+// MFMAs of a 32-deep k-tile (priority raised) while the OTHER issues the 12 fragment reads of its next k-tile and its
+// share of the LDS-DMA; the roles swap at each barrier.  Group 1 runs one slot behind group 0.
+//
+// LDS: ring of 4 slots x (256 + 256 rows x 64 B) = 128 KiB; k-tile t lives in ring slot t % 4.  A 64-B row holds 4
+// 16-B chunks; chunk c of row r is stored at c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31} + 32) then hit 16 distinct 16-B bank groups.
+//
+// Schedule (slot j, k-tile t; both groups read the same tile sequence):
+//   group 0: slot 2t   reads fragments of t, issues DMA of t+2;            slot 2t+1 MFMAs of t, then vmcnt
+//   group 1: slot 2t+1 reads fragments of t, issues DMA of t+3, vmcnt;     slot 2t+2 MFMAs of t
+// RAW: tile T is first read in slot 2T; every wave retires its own pieces of T with a counted vmcnt at the end of slot
+//      2T-1, before the barrier that opens slot 2T (group 0 then has T+1 in flight -> vmcnt(4); group 1 has T+1, T+2
+//      -> vmcnt(8)).  The read happens one slot AFTER the wait, never in the same slot.
+// Measured (in-proj 7072x2304x768, MI355X; tools/gemm_timeline.py, tools/build_variant.sh ablations): bit-identical
+// to the lock-step 256x256 kernel and 3-8 % faster (30.8-32.3 vs 32.8-34.7 us across boxes).  A slot takes ~830 cycles
+// for 512 cycles of MFMA: the LOAD side is the long one (~700: 12 ds_read_b128 + 4 LDS-DMA per wave), the compute
+// side ~600.  Ablations: without the in-loop DMA the kernel drops to 25.1 us (~600-cycle slots), without the fragment
+// reads only to 30.8 us, so the 16 LDS-DMA instructions per slot (16 KiB into LDS) cost ~270 cycles of critical path
+// wherever they are issued -- before the reads (slower), inside the MFMA stream (same), split over both groups
+// (slower); hot (L2-resident) source addresses or dropping the vmcnt waits change nothing, i.e. it is the CU-side
+// DMA path (TA at 64 B/clk plus its LDS writes), not memory latency.
+// WAR: tile t is last read by group 1 in slot 2t+1 and those ds_reads have retired (lgkmcnt) inside slot 2t+2; its ring
+//      slot is refilled with tile t+4 by group 1 in slot 2t+3 and by group 0 in slot 2t+4, both behind a barrier.
+struct CfgPP {
+  static constexpr int WAVES_M = 2, WAVES_N = 4, WM_T = 4, WN_T = 2, NWAVES = 8, THREADS = 512;
+  static constexpr int BM = 256, BN = 256, BK = 32, NRING = 4, ROWB = 64;
+  static constexpr int A_BYTES = BM * ROWB, SLOT_BYTES = (BM + BN) * ROWB;
+  static constexpr bool PRECONV_EPI = true;
+  static constexpr int CROW_BYTES(bool) { return BN * 2 + 16; }
+  static constexpr int EPI_BYTES = BM * (BN * 2 + 16);
+  static constexpr int SMEM = NRING * SLOT_BYTES > EPI_BYTES ? NRING * SLOT_BYTES : EPI_BYTES;
+  static constexpr int PIECES = 4;     // DMA instructions per wave per k-tile: 2 A + 2 W (16 rows x 64 B each)
+};
+
+template <int N> __device__ __forceinline__ void pp_vmwait(int later) {   // `later` tiles of mine may stay in flight
+  if (later >= 2) wait_vmcnt<2 * N>();
+  else if (later == 1) wait_vmcnt<N>();
+  else wait_vmcnt<0>();
+}
+
+
+template <typename TOut, int EPI>
+__global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using CF = CfgPP;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / CF::WAVES_N, wn = wave % CF::WAVES_N;
+  RPO_STAMP(0);
+  int m0, n0;
+  tile_origin<CF::BM, CF::BN>(p, m0, n0);
+  if (p.skip_row0 >= 0 && m0 >= p.skip_row0 && n0 >= p.skip_col0) return;
+  const int nk = p.K / CF::BK;
+
+  // DMA: one instruction = 16 rows x 64 B; wave w owns pieces w and 8 + w of the A tile and of the W tile.
+  // lane -> row 16 * piece + (lane >> 2), physical chunk lane & 3, which receives logical chunk (lane & 3) ^ ((row >> 2) & 3)
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* ga[2];
+  const char* gw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * (i * 8 + wave) + (lane >> 2);
+    const int lc = (lane & 3) ^ ((row >> 2) & 3);
+    ga[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda * 2 + lc * 16;
+    gw[i] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw * 2 + lc * 16;
+  }
+  auto dma = [&](int t) {
+    char* b_ = smem + (t & 3) * CF::SLOT_BYTES + wave * 1024;
+    const int64_t ko = (int64_t)t * (CF::BK * 2);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ga[0] + ko), (lptr_t)(b_), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(gw[0] + ko), (lptr_t)(b_ + CF::A_BYTES), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ga[1] + ko), (lptr_t)(b_ + 8 * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(gw[1] + ko), (lptr_t)(b_ + CF::A_BYTES + 8 * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[CF::WN_T][CF::WM_T];
+#pragma unroll
+  for (int a = 0; a < CF::WN_T; ++a)
+#pragma unroll
+    for (int b = 0; b < CF::WM_T; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  // fragment addresses inside a ring slot: rows wm*128 + tm*32 + l31 (A) / wn*64 + tn*32 + l31 (W); the swizzle term
+  // (row >> 2) & 3 depends on l31 only.  k-step ks (16 deep) = chunks 2*ks + half.
+  const int sw = (l31 >> 2) & 3;
+  const int offx = (wm * 128 + l31) * CF::ROWB, offw = CF::A_BYTES + (wn * 64 + l31) * CF::ROWB;
+  const int c0 = ((0 + half) ^ sw) << 4, c1 = ((2 + half) ^ sw) << 4;
+  bf16x8_t xf[2][CF::WM_T], wf[2][CF::WN_T];
+  auto ldfrags = [&](int t) {
+    const char* st = smem + (t & 3) * CF::SLOT_BYTES;
+#pragma unroll
+    for (int tn = 0; tn < CF::WN_T; ++tn) {
+      wf[0][tn] = *reinterpret_cast<const bf16x8_t*>(st + offw + tn * 32 * CF::ROWB + c0);
+      wf[1][tn] = *reinterpret_cast<const bf16x8_t*>(st + offw + tn * 32 * CF::ROWB + c1);
+    }
+#pragma unroll
+    for (int tm = 0; tm < CF::WM_T; ++tm) {
+      xf[0][tm] = *reinterpret_cast<const bf16x8_t*>(st + offx + tm * 32 * CF::ROWB + c0);
+      xf[1][tm] = *reinterpret_cast<const bf16x8_t*>(st + offx + tm * 32 * CF::ROWB + c1);
+    }
+  };
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < CF::WM_T; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#ifdef RPO_TIMELINE
+  // per-section cycle sums of this wave (no stores inside the loop: a store would count in vmcnt)
+  unsigned long long tl_load = 0, tl_lbar = 0, tl_comp = 0, tl_cbar = 0, tl_0, tl_1;
+#define PP_T0() tl_0 = __builtin_amdgcn_s_memtime()
+#define PP_ACC(v) do { tl_1 = __builtin_amdgcn_s_memtime(); v += tl_1 - tl_0; tl_0 = tl_1; } while (0)
+#else
+#define PP_T0() do { } while (0)
+#define PP_ACC(v) do { } while (0)
+#endif
+  if (wm == 0) {
+    // prologue: tiles 0, 1 in flight; tile 0 retired before the barrier that opens slot 0
+    if (0 < nk) dma(0);
+    if (1 < nk) dma(1);
+    pp_vmwait<CF::PIECES>(min(nk - 1, 1));
+    slot_end();
+    RPO_STAMP(2);
+    PP_T0();
+    for (int t = 0; t < nk; ++t) {
+      // slot 2t: load
+      ldfrags(t);
+      if (t + 2 < nk) dma(t + 2);
+      PP_ACC(tl_load);
+      slot_end();
+      PP_ACC(tl_lbar);
+      // slot 2t+1: compute, then retire my pieces of tile t+1 (tile t+2 may stay in flight)
+      mfmas();
+      pp_vmwait<CF::PIECES>(t + 2 < nk ? 1 : 0);
+      PP_ACC(tl_comp);
+      slot_end();
+      PP_ACC(tl_cbar);
+    }
+    slot_end();                        // slot 2nk: group 1 computes its last tile
+  } else {
+    if (0 < nk) dma(0);
+    if (1 < nk) dma(1);
+    if (2 < nk) dma(2);
+    pp_vmwait<CF::PIECES>(min(nk - 1, 2));
+    slot_end();
+    slot_end();                        // slot 0: group 0 loads its first tile
+    PP_T0();
+    for (int t = 0; t < nk; ++t) {
+      // slot 2t+1: load, DMA, retire my pieces of tile t+1 (t+2, t+3 may stay in flight)
+      ldfrags(t);
+      if (t + 3 < nk) dma(t + 3);
+      pp_vmwait<CF::PIECES>(min(nk - 1, t + 3) - min(nk - 1, t + 1));
+      PP_ACC(tl_load);
+      slot_end();
+      PP_ACC(tl_lbar);
+      // slot 2t+2: compute
+      mfmas();
+      PP_ACC(tl_comp);
+      slot_end();
+      PP_ACC(tl_cbar);
+    }
+  }
+#ifdef RPO_TIMELINE
+  if (g_timeline != nullptr && lane == 0 && (wave == 0 || wave == 4) && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) {
+    unsigned long long* o = g_timeline + (blockIdx.x / 97) * 64 + 40 + (wave >> 2) * 4;
+    o[0] = tl_load; o[1] = tl_lbar; o[2] = tl_comp; o[3] = tl_cbar;
+  }
+#endif
+  RPO_STAMP(60);
+  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0);
+#ifdef RPO_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(61);
+}
+
+template <typename TOut, int EPI>
+int launch_pp(const GemmParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_pp_kernel<TOut, EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       CfgPP::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles = ((p.M + CfgPP::BM - 1) / CfgPP::BM) * ((p.N + CfgPP::BN - 1) / CfgPP::BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1), dim3(CfgPP::THREADS), CfgPP::SMEM, s, p);
+  return rpo_launch_status();
 }
 
 template <typename TIn, typename TOut, int EPI, typename CF>
@@ -433,9 +662,11 @@ int launch(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = (tiles + 255) / 256;
     const bool fills = tiles * 100 >= rounds * 256 * 85;
-    if (p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C) &&
-        (p.force_cfg == 3 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills)))
-      return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
+    const bool ok = p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C);
+    // the ping-pong kernel is bit-identical to CfgBig and 3-8 % faster; CfgBig stays selectable (tile_config 3)
+    if (ok && (p.force_cfg == 7 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills)))
+      return launch_pp<TOut, EPI>(p, s);
+    if (ok && p.force_cfg == 3) return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
   }
   // small-M GEMMs (prompt rows: backward, text tower) are a latency chain on few CUs: 64x64 tiles give 4x
   // the workgroups and half the per-k-tile DMA issue per wave (da 9.2 -> 5.9 us, text c_proj 19.7 -> 11.3 us);

@@ -139,6 +139,40 @@ def test_gemm_many_tiles_all_epilogues(mode, M, N, K):
         assert torch.equal(out, out2), "tile shape must not change the result bits"
 
 
+@pytest.mark.parametrize("M,N,K", [(7072, 2304, 768), (4096, 4096, 64), (2048, 1536, 128), (7000, 2304, 192),
+                                   (6500, 2560, 3072)])
+def test_gemm_pingpong_256_bit_identical_and_race_screen(M, N, K):
+    """The 256x256 ping-pong kernel (tile_config 7; what the heuristic picks for the image in-proj): against
+    float64, bit-identical to the lock-step 256x256 and 128x128 kernels (same k-order per output), M tails, K from
+    two 32-deep tiles up to 96, and a race screen -- 25 back-to-back launches must all give the same bits."""
+    from rpo_amd import _lib as L
+    o = ops()
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias = rnd((N,), 3)
+    acc = q(a, "bf16") @ q(w, "bf16").t()
+    ad, wd, bd = a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), bias.to(dev())
+    row0 = M - 300
+    for epi, ref in ((L.EPI_BIAS, acc + bias.double()), (L.EPI_BIAS_QGELU, R.qgelu(acc + bias.double()))):
+        outs = {}
+        for cfg in (7, 3, 2, 0):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+            kw = dict(bias=bd)
+            if epi == L.EPI_BIAS_QGELU:
+                kw.update(aux_row0=row0, aux=torch.full((M - row0, N), float("nan"), device=dev()))
+            o.gemm_nt(ad, wd, out, epi, tile_config=cfg, **kw)
+            outs[cfg] = (out, kw.get("aux"))
+        close(outs[7][0], ref, "bf16", f"pingpong gemm epi {epi}")
+        for cfg in (3, 2, 0):
+            assert torch.equal(outs[7][0], outs[cfg][0]), f"tile_config {cfg} differs from the ping-pong kernel"
+            if epi == L.EPI_BIAS_QGELU:
+                assert torch.equal(outs[7][1], outs[cfg][1])
+        if epi == L.EPI_BIAS:
+            for _ in range(25):
+                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+                o.gemm_nt(ad, wd, out, epi, tile_config=7, bias=bd)
+                assert torch.equal(out, outs[7][0]), "ping-pong kernel is not deterministic: LDS race"
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_gemm_split_k_feeds_layernorm_bwd(mode):
     """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""

@@ -7,7 +7,7 @@ import torch
 from rpo_amd import _lib, ops
 from rpo_amd._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
-src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip")]
+src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip")]
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRPO_TIMELINE", "-fgpu-rdc", *src, "-o", dbg])
@@ -19,7 +19,8 @@ buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
 for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), 
                                      ("c_proj_tall", 7072, 768, 3072, EPI_NONE, torch.float32, 6), ("one_wg_mid", 128, 128, 3072, EPI_NONE, torch.float32, 2),
-                                     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 0)]:
+                                     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 3),
+                                     ("qkv_pingpong (stamps per 32-deep k-tile)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 7)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=odt, device=dev); bias = torch.randn(N, device=dev)
     for _ in range(3):
@@ -33,4 +34,10 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
         if r[0] == 0: continue
         nk = int((r[2:52] != 0).sum())
         deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
+        if cfg == 7:
+            nk32 = K // 32
+            g = lambda i: int(r[40 + i]) // nk32
+            print(f" wg {b*97:5d}: start->loop {int(r[2]-r[0]):6d} | loop {int(r[60]-r[2]):6d} = {nk32} tiles x {int(r[60]-r[2])//nk32} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}"
+                  f" || per tile, group 0: load {g(0)} bar {g(1)} compute {g(2)} bar {g(3)}; group 1: load {g(4)} bar {g(5)} compute {g(6)} bar {g(7)}")
+            continue
         print(f" wg {b*97:5d}: start->tile0 {int(r[2]-r[0]):6d} | per-k-tile {deltas} | last-tile->epi {int(r[60]-r[2+nk-1]):6d} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])} || wave0 per-iter: vmcnt-wait {int(r[53])//max(nk,1)} barrier {int(r[54])//max(nk,1)} body(issue) {int(r[55])//max(nk,1)}")
