@@ -16,6 +16,14 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_step_$c -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision > $O/pmc_step_$c.log 2>&1
 done
+# the other BASELINE.json configs and the widened rows through the same bench.py
+B="--no-cpu-baseline --no-precision"
+timeout 200 python bench.py --model ViT-L/14 --batch 16 --steps 30 --warmup 5 $B > $O/bench_vitl14.json 2>> $O/bench.err
+: > $O/bench_ksweep.json
+for k in 4 8 16 24 48; do timeout 200 python bench.py --K $k --steps 30 --warmup 5 $B >> $O/bench_ksweep.json 2>> $O/bench.err; done
+timeout 200 python bench.py --dtype f32 --steps 20 --warmup 5 $B > $O/bench_f32.json 2>> $O/bench.err
+timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench_eval.json 2>> $O/bench.err
+timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
 ls $O

@@ -17,7 +17,7 @@ if db:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n"
                 "# NB: kernel tracing serialises the two HIP queues; per-kernel durations are valid, overlap is not.\n")
         f.write(txt + "\n# last step:\n" + tl)
-SH = {"qkv": "in-proj 7072x2304x768 bias (256x256 tiles), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
+SH = {"qkv": "in-proj 7072x2304x768 bias (256x256 ping-pong kernel), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
       "out_proj": "out-proj 7072x768x768 bias+residual (64x128 tiles), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
       "c_fc": "c_fc 7072x3072x768 bias+QuickGELU (128x128 tiles), 33.4 GFLOP, 10.9+4.7+43.4 MB",
       "c_proj": "c_proj 7072x768x3072 bias+residual (64x128 tiles), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
@@ -36,7 +36,7 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if "gemm_nt_kernel" in r["Kernel_Name"]:
+            if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, x in agg.items():
             vals[k] = sum(x) / len(x)
@@ -70,6 +70,10 @@ if step:
             fo.write(f"{k} {v:.6g}\n")
         if "FETCH_SIZE" in step and "WRITE_SIZE" in step:
             fo.write(f"traffic_bytes_per_step {(2 * step['FETCH_SIZE'] + step['WRITE_SIZE']) * 1024:.6g}\n")
+for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_eval.json", "bench_input_pipeline.json"):
+    src = os.path.join(raw, fn)
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
 for fn in ("gemm_timeline.txt", "graph_phases.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
