@@ -123,3 +123,19 @@ def flops_text(cfg: RPOConfig, len_prompts) -> float:
 def flops_step(cfg: RPOConfig, batch: int, len_prompts) -> float:
     f, b = flops_image(cfg)
     return batch * (f + b) + flops_text(cfg, len_prompts) + batch * 2.0 * cfg.K * cfg.embed * cfg.n_cls
+
+
+def act_dtype_for_prec(prec: str):
+    """`TRAINER.RPO.PREC` (configs/trainers/RPO/main_K24.yaml:35, trainers/rpo.py:247-249,278,298-304) -> the
+    activation / weight storage dtype of the HIP engine.
+
+    "fp32": exact-f32 MFMA path (the parity mode).  "fp16" (the reference's GPU default: fp16 weights and prompts,
+    plain SGD, no loss scaling) and "amp" (fp32 master weights, autocast forward, GradScaler) both map to the bf16
+    storage mode: bf16 weights / activations, fp32 accumulation, fp32 residual stream, fp32 prompts and optimiser
+    state.  That is the same "16-bit tensors, 32-bit accumulate" contract with fp32 range, so no loss scaling is
+    needed and there is no GradScaler counterpart; a native fp16 storage mode is not implemented."""
+    import torch
+    table = {"fp32": torch.float32, "fp16": torch.bfloat16, "amp": torch.bfloat16}
+    if prec not in table:
+        raise ValueError(f"TRAINER.RPO.PREC must be one of {sorted(table)} (trainers/rpo.py:247), got {prec!r}")
+    return table[prec]

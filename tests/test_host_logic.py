@@ -153,3 +153,12 @@ def test_subsample_classes_and_fewshot():
     assert len(few) == 3
     rep = generate_fewshot_dataset(base_tr[:3], 16, repeat=True, rng=random.Random(0))
     assert len(rep) == 16
+
+
+def test_prec_mapping():
+    import torch
+    from rpo_amd.config import act_dtype_for_prec
+    assert act_dtype_for_prec("fp32") is torch.float32
+    assert act_dtype_for_prec("fp16") is torch.bfloat16 and act_dtype_for_prec("amp") is torch.bfloat16
+    with pytest.raises(ValueError):
+        act_dtype_for_prec("int8")
