@@ -113,7 +113,10 @@ struct Cfg {
 #define RPO_SPREAD_TINY 2
 #define RPO_SPREAD_TALL 4
 #endif
-using CfgMid = Cfg<2, 4, 2, 1, 2, RPO_SPREAD_MID>;
+#ifndef RPO_MID_STAGES
+#define RPO_MID_STAGES 2
+#endif
+using CfgMid = Cfg<2, 4, 2, 1, RPO_MID_STAGES, RPO_SPREAD_MID>;
 using CfgBig = Cfg<2, 4, 4, 2, 2, RPO_SPREAD_BIG>;
 // The 64x64 tiles serve the prompt-row GEMMs (backward, text tower): latency chains of ~170 small kernels whose
 // inputs were just written by the previous kernel, i.e. come from MALL / HBM, not L2.  A third LDS stage (one more
@@ -144,7 +147,10 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }
-  constexpr int GM = 8;
+#ifndef RPO_GM
+#define RPO_GM 8
+#endif
+  constexpr int GM = RPO_GM;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GM * tiles_n;
   const int grp = wg / per_group;
@@ -671,7 +677,10 @@ int launch(const GemmParams& p, hipStream_t s) {
     // (in-proj at B=32: 252 tiles; c_fc: 336 tiles = 1.3 rounds -> 65 us vs 55 us with 128x128)
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = (tiles + 255) / 256;
-    const bool fills = tiles * 100 >= rounds * 256 * 85;
+#ifndef RPO_FILL_PCT
+#define RPO_FILL_PCT 85
+#endif
+    const bool fills = tiles * 100 >= rounds * 256 * RPO_FILL_PCT;
     const bool ok = p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C);
     // the ping-pong kernel is bit-identical to CfgBig and 3-8 % faster; CfgBig stays selectable (tile_config 3)
     if (ok && (p.force_cfg == 7 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills)))
@@ -682,7 +691,10 @@ int launch(const GemmParams& p, hipStream_t s) {
   // the workgroups and half the per-k-tile DMA issue per wave (da 9.2 -> 5.9 us, text c_proj 19.7 -> 11.3 us);
   // N <= 1024 at large M (out_proj, c_proj) prefers 64x128 (more workgroups than 128x128's 336)
   if (p.force_cfg == 5 || (p.force_cfg == 0 && p.M < 2048)) return launch_cfg<TIn, TOut, EPI, CfgTiny>(p, s);
-  if (p.force_cfg == 6 || (p.force_cfg == 0 && p.N <= 1024)) return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
+#ifndef RPO_TALL_N
+#define RPO_TALL_N 1024
+#endif
+  if (p.force_cfg == 6 || (p.force_cfg == 0 && p.N <= RPO_TALL_N)) return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
   return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
 }
 
