@@ -691,7 +691,10 @@ int launch(const GemmParams& p, hipStream_t s) {
   // small-M GEMMs (prompt rows: backward, text tower) are a latency chain on few CUs: 64x64 tiles give 4x
   // the workgroups and half the per-k-tile DMA issue per wave (da 9.2 -> 5.9 us, text c_proj 19.7 -> 11.3 us);
   // N <= 1024 at large M (out_proj, c_proj) prefers 64x128 (more workgroups than 128x128's 336)
-  if (p.force_cfg == 5 || (p.force_cfg == 0 && p.M < 2048)) return launch_cfg<TIn, TOut, EPI, CfgTiny>(p, s);
+#ifndef RPO_TINY_MAXN
+#define RPO_TINY_MAXN (1 << 30)
+#endif
+  if (p.force_cfg == 5 || (p.force_cfg == 0 && p.M < 2048 && p.N <= RPO_TINY_MAXN)) return launch_cfg<TIn, TOut, EPI, CfgTiny>(p, s);
 #ifndef RPO_TALL_N
 #define RPO_TALL_N 1024
 #endif

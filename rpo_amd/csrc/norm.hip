@@ -7,17 +7,23 @@
 // the same formula torch's CPU kernel evaluates.
 #include "common.h"
 
+// rows (= waves) per workgroup.  One row per workgroup spreads the 768-row LayerNorms of the backward chains over
+// all CUs (step-level A/B: 4 -> 1 rows per workgroup = -0.6 % step time; the 7 072-row forward ones do not care).
+#ifndef RPO_LN_RPB
+#define RPO_LN_RPB 1
+#endif
+
 namespace {
 
 constexpr int MAXV = 8;   // float4 per lane: d <= 64 * 4 * 8 = 2048 (kernels are templated on the count)
 
 template <typename TY, int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* y, int64_t ldy,
                                                      int rows, int d, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
@@ -69,7 +75,7 @@ template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 template <typename TDY, typename TC, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
                                                      const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, int64_t lddres,
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      int rows, int d, float eps, int splits,
                                                      int64_t split_stride) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
@@ -156,7 +162,7 @@ extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   if (d % 4 != 0 || d > 64 * 4 * MAXV) return RPO_E_SHAPE;
   if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || ldx % 4 != 0 || ldy % 4 != 0) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((rows + 3) / 4), block(256);
+  const dim3 grid((rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
   const int nv = (d / 4 + 63) / 64;
 #define RPO_LN_FWD(TY, NV)                                                                          \
   hipLaunchKernelGGL((ln_fwd_kernel<TY, NV>), grid, block, 0, s, x, ldx, gamma, beta, static_cast<TY*>(y), \
@@ -193,7 +199,7 @@ extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, con
   if (dx_cast && (reinterpret_cast<uintptr_t>(dx_cast) % 8 || ldcast % 4)) return RPO_E_ALIGN;
   if (reinterpret_cast<uintptr_t>(dy) % (dy_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((rows + 3) / 4), block(256);
+  const dim3 grid((rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
   const int nv = (d / 4 + 63) / 64;
 #define RPO_LN_BWD_(TDY, TC, NV)                                                                          \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC, NV>), grid, block, 0, s, static_cast<const TDY*>(dy), lddy, \
