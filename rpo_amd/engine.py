@@ -32,10 +32,9 @@ from .config import RPOConfig
 SCALE = 1.0 / math.sqrt(64.0)
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
 # d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.
-import os as _os
-# split-K of the two dX GEMMs that feed rpo_layernorm_bwd (measured at step level; more slabs cost output bandwidth).
-# RPO_SPLIT_FC / RPO_SPLIT_Q override them for tuning runs.
-SPLIT_FC, SPLIT_Q = int(_os.environ.get("RPO_SPLIT_FC", 3)), int(_os.environ.get("RPO_SPLIT_Q", 2))
+# split-K of the two dX GEMMs that feed rpo_layernorm_bwd, tuned at step level (3 / 2; 4, 6, 8 slabs for c_fc and 3, 4 for
+# the q-projection were slower: more slabs cost output bandwidth, fewer leave CUs idle)
+SPLIT_FC, SPLIT_Q = 3, 2
 
 
 def _round_up(x: int, m: int) -> int:
