@@ -31,9 +31,8 @@ from .config import RPOConfig
 
 SCALE = 1.0 / math.sqrt(64.0)
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
-# d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.
-# split-K of the two dX GEMMs that feed rpo_layernorm_bwd, tuned at step level (3 / 2; 4, 6, 8 slabs for c_fc and 3, 4 for
-# the q-projection were slower: more slabs cost output bandwidth, fewer leave CUs idle)
+# d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.  Tuned at step level:
+# 4, 6, 8 slabs for c_fc and 3, 4 for the q-projection were slower (more slabs cost output bandwidth).
 SPLIT_FC, SPLIT_Q = 3, 2
 
 
