@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from rpo_amd import synth  # noqa: E402
-from rpo_amd.config import flops_image, flops_step, flops_text, vit_b16, vit_l14  # noqa: E402
+from rpo_amd.config import flops_image, flops_last_block_dead, flops_step, flops_text, vit_b16, vit_l14  # noqa: E402
 from rpo_amd.dist import GradSync  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # /opt/skills/guides/MI355X_MICROARCH.md
@@ -310,6 +310,9 @@ def main() -> None:
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/step/GPU",
                      "traffic_source": traffic_src,
                      "algorithmic_gflop_per_step_per_gpu": round(fl_step / 1e9, 2),
+                     # the contract figure above counts the last block's frozen rows in full; the engine skips their
+                     # dead q / attention / out-proj / MLP work, so it EXECUTES less than it is credited with:
+                     "executed_gflop_per_step_per_gpu": round((fl_step - args.batch * flops_last_block_dead(cfg)) / 1e9, 2),
                      "gflop_per_image": round(sum(flops_image(cfg)) / 1e9, 2),
                      "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2)},
     }

@@ -142,6 +142,11 @@ int rpo_reduce_groups(const float* src, int64_t ld, float* out, int groups, int 
 int rpo_attn_readonly_fwd(const void* q, const void* k, const void* v, int64_t ld,
                           void* out, int64_t ldo, int dtype, int B, int H, int N, int Kp,
                           float scale, void* stream);
+/* Same, computing only the queries q_first .. N+Kp-1 of every image (earlier rows of `out` are left untouched).  The
+ * last block of the image tower needs the prompt queries only: ln_post reads nothing else (trainers/rpo.py:210). */
+int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld,
+                               void* out, int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
+                               int q_first, void* stream);
 
 /* Backward of the above for the prompt rows only: dq[B*Kp, lddq] given da[B*Kp, ldda].
  * q_rows points at the first PROMPT row of q; k, v at the first frozen row.  dK/dV are not

@@ -125,6 +125,14 @@ def flops_step(cfg: RPOConfig, batch: int, len_prompts) -> float:
     return batch * (f + b) + flops_text(cfg, len_prompts) + batch * 2.0 * cfg.K * cfg.embed * cfg.n_cls
 
 
+def flops_last_block_dead(cfg: RPOConfig) -> float:
+    """FLOPs per image that flops_image (the SURVEY 8d contract figure) counts but the engine does not execute: in the
+    LAST image block only the K prompt rows are consumed (ln_post, trainers/rpo.py:210), so the N frozen rows skip
+    their q-projection, attention, out-proj and MLP (they still provide K / V)."""
+    d, N = cfg.d_v, cfg.n_frozen
+    return float(20 * N * d * d + 4 * N * N * d)
+
+
 def act_dtype_for_prec(prec: str):
     """`TRAINER.RPO.PREC` (configs/trainers/RPO/main_K24.yaml:35, trainers/rpo.py:247-249,278,298-304) -> the
     activation / weight storage dtype of the HIP engine.

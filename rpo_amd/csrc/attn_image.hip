@@ -286,7 +286,8 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
 template <typename T, int NT>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, int64_t ld, T* out,
-                                                       int64_t ldo, int B, int H, int N, int Kp, float scale) {
+                                                       int64_t ldo, int B, int H, int N, int Kp, float scale,
+                                                       int q_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -305,7 +306,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     return sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
   };
   RowFrag<T> qf;
-  if constexpr (sizeof(T) == 2) qf.load(q + qrow(wave) * ld + h * 64, half);   // (f32: 32 live VGPRs too many)
+  // q_first > 0: only queries q_first .. S-1 of every image are wanted (last block: the prompt rows); whole
+  // 32-query tiles are skipped, the leading queries of the first computed tile are computed but not stored
+  const int qt0 = q_first >> 5;
+  if constexpr (sizeof(T) == 2) qf.load(q + qrow(qt0 + wave) * ld + h * 64, half);   // (f32: 32 live VGPRs too many)
   if constexpr (sizeof(T) == 2) {
     bf16x8_t vrows[(NT + 7) / 8][4];
 #pragma unroll
@@ -344,14 +348,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   __syncthreads();
   RPO_STAMP(3);
 
-  for (int qt = wave; qt * 32 < S; qt += 8) {
+  for (int qt = qt0 + wave; qt * 32 < S; qt += 8) {
     // K/V fragments in LDS do not depend on the query tile; without this opaque copy the
     // compiler hoists all of their ds_reads out of the loop and spills them to scratch
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
     const int s = qt * 32 + l31;
     const int64_t grow = qrow(qt);
-    if (sizeof(T) != 2 || qt != wave) qf.load(q + grow * ld + h * 64, half);
+    if (sizeof(T) != 2 || qt != qt0 + wave) qf.load(q + grow * ld + h * 64, half);
     // online softmax over the key tiles (running max m, running sum l, output rescaled when m grows): only one
     // score tile is live, so the kernel fits 128 VGPRs and TWO workgroups share a CU -- the 384 (image, head)
     // workgroups of a B=32 launch are then all resident at once instead of running in two rounds.
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (s < S) {
+    if (s < S && s >= q_first) {
       T* orow = out + grow * ldo + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
 
 template <typename T, int NT>
 int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
-               int N, int Kp, float scale, hipStream_t s) {
+               int N, int Kp, float scale, int q_first, hipStream_t s) {
   static bool attr_set = false;
   auto kern = attn_fwd_kernel<T, NT>;
   constexpr int bytes = AL<T, NT>::FWD_BYTES;
@@ -542,7 +546,7 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
   }
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),
                      static_cast<const T*>(k), static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H,
-                     N, Kp, scale);
+                     N, Kp, scale, q_first);
   return rpo_launch_status();
 }
 
@@ -568,10 +572,21 @@ bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
 
 }  // namespace
 
+extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld, void* out,
+                                          int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
+                                          int q_first, void* stream);
+
 extern "C" int rpo_attn_readonly_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out,
                                      int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
                                      void* stream) {
-  if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Kp < 0) return RPO_E_BADARG;
+  return rpo_attn_readonly_fwd_rows(q, k, v, ld, out, ldo, dtype, B, H, N, Kp, scale, 0, stream);
+}
+
+extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld, void* out,
+                                          int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
+                                          int q_first, void* stream) {
+  if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Kp < 0 || q_first < 0 || q_first >= N + Kp)
+    return RPO_E_BADARG;
   if (N > 288) return RPO_E_SHAPE;
   if (dtype != RPO_F32 && dtype != RPO_BF16) return RPO_E_DTYPE;
   const int esz = dtype == RPO_BF16 ? 2 : 4;
@@ -579,11 +594,11 @@ extern "C" int rpo_attn_readonly_fwd(const void* q, const void* k, const void* v
       reinterpret_cast<uintptr_t>(out) % (4 * esz) || (ldo * esz) % (4 * esz)) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == RPO_BF16) {
-    if (N <= 224) return launch_fwd<bf16_t, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
-    return launch_fwd<bf16_t, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+    if (N <= 224) return launch_fwd<bf16_t, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+    return launch_fwd<bf16_t, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
   }
-  if (N <= 224) return launch_fwd<float, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
-  return launch_fwd<float, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, s);
+  if (N <= 224) return launch_fwd<float, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+  return launch_fwd<float, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
 }
 
 extern "C" int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const void* v,

@@ -247,17 +247,29 @@ class Engine:
         ops.img_assemble(x_pre, self.cls, self.pos, self.img_prompt, B, N, K)          # rpo.py:201-204
         ops.layernorm_fwd(x_pre, self.ln_pre[0], self.ln_pre[1], self.x[0][:R])        # rpo.py:206
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
+        last = len(self.vis) - 1
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
             ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
-            # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
-            ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
-            ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
-            ops.gemm_nt(att, blk.w_out, xm, EPI_BIAS_RESID, bias=blk.b_out, resid=x)
-            ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, h)
-            ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc,
-                        aux=self.u[l][:Rp] if train else None, aux_row0=Rf)
-            ops.gemm_nt(g, blk.w_proj, xo, EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
+            if l < last:
+                # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
+                ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
+                ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
+                lo = 0
+            else:
+                # Last block: only its K prompt rows are consumed (ln_post reads x[:, -K:], rpo.py:210; the CLS feature
+                # i_f of :211 is dead code), and no later block reads the frozen rows.  So the frozen rows contribute
+                # their K / V and nothing else: q and everything after attention run on the B*K prompt rows only.
+                ops.gemm_nt(h[:Rf], blk.w_in[dv:], qkv[:Rf, dv:], EPI_BIAS, bias=blk.b_in[dv:])
+                ops.gemm_nt(h[Rf:], blk.w_in[:dv], qkv[Rf:, :dv], EPI_BIAS, bias=blk.b_in[:dv])
+                ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE,
+                                      q_first=N)
+                lo = Rf
+            ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:])
+            ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
+            ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
+                        aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
+            ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:])
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

@@ -125,11 +125,12 @@ def reduce_groups(src: torch.Tensor, out: torch.Tensor, groups: int) -> torch.Te
     return out
 
 
-def attn_readonly_fwd(q, k, v, out, B: int, H: int, N: int, Kp: int, scale: float = 0.125):
+def attn_readonly_fwd(q, k, v, out, B: int, H: int, N: int, Kp: int, scale: float = 0.125, q_first: int = 0):
+    """q_first > 0: only queries q_first .. N+Kp-1 of every image (the prompt rows when q_first = N)."""
     assert _ld(q) == _ld(k) == _ld(v)
-    check(_lib.load().rpo_attn_readonly_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(q), out.data_ptr(),
-                                            _ld(out), dtype_code(q.dtype), B, H, N, Kp, scale, _stream()),
-          "rpo_attn_readonly_fwd")
+    check(_lib.load().rpo_attn_readonly_fwd_rows(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(q), out.data_ptr(),
+                                                 _ld(out), dtype_code(q.dtype), B, H, N, Kp, scale, q_first, _stream()),
+          "rpo_attn_readonly_fwd_rows")
     return out
 
 
