@@ -535,15 +535,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
 template <typename T, int NT>
 int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
                int N, int Kp, float scale, int q_first, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long lds_ok = 0;
   auto kern = attn_fwd_kernel<T, NT>;
   constexpr int bytes = AL<T, NT>::FWD_BYTES;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),
                      static_cast<const T*>(k), static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H,
                      N, Kp, scale, q_first);
@@ -553,15 +548,10 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
 template <typename T, int NT>
 int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* da,
                int64_t ldda, void* dq, int64_t lddq, int B, int H, int N, int Kp, float scale, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long lds_ok = 0;
   auto kern = attn_bwd_kernel<T, NT>;
   constexpr int bytes = AL<T, NT>::BWD_BYTES;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
                      static_cast<T*>(dq), lddq, B, H, N, Kp, scale);

@@ -120,15 +120,10 @@ template <typename T, bool BWD>
 int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
            int64_t ldda, void* out, int64_t ldo, const int32_t* len, int n_cls, int rows, int Lmax, int H,
            int causal, float scale, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long lds_ok = 0;
   auto kern = text_attn_kernel<T, BWD>;
   const int bytes = 2 * Lmax * 65 * 4;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 65 * 4);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), 2 * 128 * 65 * 4, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(n_cls * H, (rows + 3) / 4), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
                      static_cast<const T*>(kc), static_cast<const T*>(vc), ldkv, static_cast<const T*>(da), ldda,
                      static_cast<T*>(out), ldo, len, rows, Lmax, H, causal, scale);

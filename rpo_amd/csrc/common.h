@@ -67,6 +67,20 @@ __device__ __forceinline__ float quick_gelu_grad(float u) {
   return s * (1.0f + RPO_QG * u * (1.0f - s));
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must raise the limit once per (kernel, device).  `mask` is the
+// caller's function-local static: bit d = done on device d (devices >= 64 re-set it on every launch).
+static inline int rpo_allow_lds(const void* kern, int bytes, unsigned long long* mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+  if (bit && (*mask & bit)) return 0;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  *mask |= bit;
+  return 0;
+}
+
 static inline int rpo_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

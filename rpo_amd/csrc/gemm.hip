@@ -638,14 +638,9 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long lds_ok = 0;
   auto kern = gemm_pp_kernel<TOut, EPI>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       CfgPP::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), CfgPP::SMEM, &lds_ok)) return rc;
   const int tiles = ((p.M + CfgPP::BM - 1) / CfgPP::BM) * ((p.N + CfgPP::BN - 1) / CfgPP::BN);
   hipLaunchKernelGGL(kern, dim3(tiles, 1), dim3(CfgPP::THREADS), CfgPP::SMEM, s, p);
   return rpo_launch_status();
@@ -653,14 +648,9 @@ int launch_pp(const GemmParams& p, hipStream_t s) {
 
 template <typename TIn, typename TOut, int EPI, typename CF>
 int launch_cfg(const GemmParams& p, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long lds_ok = 0;
   auto kern = gemm_nt_kernel<TIn, TOut, EPI, CF>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), CF::SMEM, &lds_ok)) return rc;
   const int tiles = ((p.M + CF::BM - 1) / CF::BM) * ((p.N + CF::BN - 1) / CF::BN);
   hipLaunchKernelGGL(kern, dim3(tiles, p.split_k), dim3(CF::THREADS), CF::SMEM, s, p);
   return rpo_launch_status();
