@@ -21,6 +21,8 @@ B="--no-cpu-baseline --no-precision"
 timeout 200 python bench.py --model ViT-L/14 --batch 16 --steps 30 --warmup 5 $B > $O/bench_vitl14.json 2>> $O/bench.err
 : > $O/bench_ksweep.json
 for k in 4 8 16 24 48; do timeout 200 python bench.py --K $k --steps 30 --warmup 5 $B >> $O/bench_ksweep.json 2>> $O/bench.err; done
+: > $O/bench_batchsweep.json
+for b in 4 8 16 64 128; do timeout 200 python bench.py --batch $b --steps 40 --warmup 5 $B >> $O/bench_batchsweep.json 2>> $O/bench.err; done
 timeout 200 python bench.py --dtype f32 --steps 20 --warmup 5 $B > $O/bench_f32.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench_eval.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err

@@ -70,7 +70,7 @@ if step:
             fo.write(f"{k} {v:.6g}\n")
         if "FETCH_SIZE" in step and "WRITE_SIZE" in step:
             fo.write(f"traffic_bytes_per_step {(2 * step['FETCH_SIZE'] + step['WRITE_SIZE']) * 1024:.6g}\n")
-for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_eval.json", "bench_input_pipeline.json"):
+for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_eval.json", "bench_input_pipeline.json", "bench_batchsweep.json"):
     src = os.path.join(raw, fn)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
