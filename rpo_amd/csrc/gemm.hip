@@ -160,9 +160,34 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
   m0 = tile_m * BM; n0 = tile_n * BN;
 }
 
+// Epilogues that read a second [M, N] operand (residual / saved pre-activation) can fetch it BEFORE the main loop when
+// the row-major pass of a thread is a single group of 4 rows (64-row tiles: 4 float4 = 16 VGPRs): the HBM round trip
+// then overlaps the k-loop instead of sitting in the epilogue.
+template <int EPI, typename CF>
+struct EpiPre {
+  static constexpr int CPR = CF::BN / 4, RPP = CF::THREADS / CPR;
+  static constexpr bool value = !CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_QGELU_BWD) && CF::BM / RPP == 4;
+};
+template <int EPI, typename CF>
+__device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0, float4 (&pre)[4]) {
+  constexpr int CPR = EpiPre<EPI, CF>::CPR, RPP = EpiPre<EPI, CF>::RPP;
+  const int tid = threadIdx.x;
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int n = n0 + cc * 4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int m = m0 + u * RPP + r0;
+    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.N && m < p.M) {
+      if (EPI == RPO_EPI_BIAS_RESID) pre[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)m * p.ldr + n);
+      else pre[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)m * p.ldaux + n);
+    }
+  }
+}
+
 template <typename TOut, int EPI, typename CF>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[CF::WN_T][CF::WM_T], char* smem,
-                                              const int m0, const int n0) {
+                                              const int m0, const int n0, const float4* pre = nullptr) {
   constexpr int BM = CF::BM, BN = CF::BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -256,7 +281,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         const int mc = min(m, p.M - 1);
         orow[u] = mc;
         ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == RPO_EPI_PATCH) {
+        if (EpiPre<EPI, CF>::value) {            // loaded before the main loop (see the kernel)
+          ex[u] = pre[u];
+        } else if (EPI == RPO_EPI_PATCH) {
           const int img = mc / p.group;
           orow[u] = (int64_t)mc + img + 1;
           if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
@@ -362,6 +389,11 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) dma(s, s);
+  float4 pre[4];
+  if constexpr (EpiPre<EPI, CF>::value) {
+    epi_preload<EPI, CF>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
+                                              // in-loop DMA, so the counted waits below stay valid (conservative)
+  }
 
 #ifdef RPO_TIMELINE
   unsigned long long t_wait = 0, t_bar = 0, t_body = 0, t_a, t_b, t_c, t_d;
@@ -433,7 +465,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 
 
   RPO_STAMP(60);
-  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0);
+  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0, pre);
 #ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
