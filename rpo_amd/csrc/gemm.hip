@@ -187,7 +187,8 @@ __device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0,
 
 template <typename TOut, int EPI, typename CF>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[CF::WN_T][CF::WM_T], char* smem,
-                                              const int m0, const int n0, const float4* pre = nullptr) {
+                                              const int m0, const int n0, const float4* pre = nullptr,
+                                              const float4* pre_bias = nullptr) {
   constexpr int BM = CF::BM, BN = CF::BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -268,7 +269,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     const int n = n0 + cc * 4;
     const bool nok = n < p.N;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    if (HAS_BIAS && pre_bias != nullptr) b4 = *pre_bias;           // fetched before the main loop
+    else if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
     TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
     for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
       float4 ex[UNR];
@@ -389,6 +391,12 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) dma(s, s);
+  // bias of this thread's 4 output columns (row-major epilogue pass), fetched now so its latency hides in the k-loop
+  float4 pre_b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (!CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID)) {
+    const int n = n0 + (tid % (CF::BN / 4)) * 4;
+    if (n < p.N) pre_b = *reinterpret_cast<const float4*>(p.bias + n);
+  }
   float4 pre[4];
   if constexpr (EpiPre<EPI, CF>::value) {
     epi_preload<EPI, CF>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
@@ -465,7 +473,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 
 
   RPO_STAMP(60);
-  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0, pre);
+  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0, pre,
+                               CF::PRECONV_EPI ? nullptr : &pre_b);
 #ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
