@@ -140,7 +140,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // resident on one XCD form a compact super-tile whose A and W panels fit its 4 MiB L2.
 template <int BM, int BN>
 __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + BN - 1) / BN;      // BM, BN are powers of two or constants: shifts / mul-shift
   int wg;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -153,10 +153,19 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
   constexpr int GM = RPO_GM;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GM * tiles_n;
-  const int grp = wg / per_group;
+  // these divisions sit in front of the first DMA of every workgroup: a float reciprocal + one correction step
+  // (exact for operands < 2^22) instead of the ~40-instruction integer sequence each
+  auto fdiv = [](int a, int b) {
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const int r = a - q * b;
+    q += (r >= b) - (r < 0);
+    return q;
+  };
+  const int grp = fdiv(wg, per_group);
   const int gm = min(GM, tiles_m - grp * GM);
   const int in_grp = wg - grp * per_group;
-  const int tile_m = grp * GM + in_grp % gm, tile_n = in_grp / gm;
+  const int tile_n = fdiv(in_grp, gm);
+  const int tile_m = grp * GM + (in_grp - tile_n * gm);
   m0 = tile_m * BM; n0 = tile_n * BN;
 }
 
