@@ -101,12 +101,16 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// unit vectors and inverse norms of every feature row (trainers/rpo.py:215-219)
-__global__ __launch_bounds__(256) void head_normalize_kernel(const float* __restrict__ f, float* unit,
-                                                             float* inv_norm, int rows, int e) {
+// unit vectors and inverse norms of every feature row (trainers/rpo.py:215-219); image rows then class rows, one launch
+__global__ __launch_bounds__(256) void head_normalize_kernel(const float* __restrict__ f_img, float* u_img, float* n_img,
+                                                             int rows_img, const float* __restrict__ f_txt, float* u_txt,
+                                                             float* n_txt, int e) {
   __shared__ float red[4];
-  const int r = blockIdx.x;
-  const float* x = f + (int64_t)r * e;
+  const bool img = (int)blockIdx.x < rows_img;
+  const int r = img ? blockIdx.x : blockIdx.x - rows_img;
+  const float* x = (img ? f_img : f_txt) + (int64_t)r * e;
+  float* unit = img ? u_img : u_txt;
+  float* inv_norm = img ? n_img : n_txt;
   float s = 0.f;
   for (int i = threadIdx.x; i < e; i += 256) s += x[i] * x[i];
   const float inv = 1.0f / sqrtf(block_sum(s, red));
@@ -115,17 +119,28 @@ __global__ __launch_bounds__(256) void head_normalize_kernel(const float* __rest
 }
 
 // logits[b,c] = (scale/K) * sum_{i,e} ih[b,i,e] th[c,i,e]   (trainers/rpo.py:221-227)
+// one block = one image x 4 classes: the image row is read once per block instead of once per class
+constexpr int HEAD_CPB = 4;
 __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ ih,
                                                           const float* __restrict__ th, float* logits, int C,
                                                           int Ke, float mul) {
   __shared__ float red[4];
-  const int c = blockIdx.x, b = blockIdx.y;
+  const int c0 = blockIdx.x * HEAD_CPB, b = blockIdx.y;
   const float* x = ih + (int64_t)b * Ke;
-  const float* y = th + (int64_t)c * Ke;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < Ke; i += 256) s = fmaf(x[i], y[i], s);
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) logits[(int64_t)b * C + c] = s * mul;
+  const float* y[HEAD_CPB];
+#pragma unroll
+  for (int j = 0; j < HEAD_CPB; ++j) y[j] = th + (int64_t)min(c0 + j, C - 1) * Ke;
+  float s[HEAD_CPB] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < Ke; i += 256) {
+    const float xv = x[i];
+#pragma unroll
+    for (int j = 0; j < HEAD_CPB; ++j) s[j] = fmaf(xv, y[j][i], s[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < HEAD_CPB; ++j) {
+    const float t = block_sum(s[j], red);
+    if (threadIdx.x == 0 && c0 + j < C) logits[(int64_t)b * C + c0 + j] = t * mul;
+  }
 }
 
 // per image: loss_b = logsumexp - logit[label]; dl[b,c] = (softmax - onehot) * gmul
@@ -158,15 +173,22 @@ __global__ void head_loss_mean_kernel(const float* __restrict__ loss_b, float* l
 
 // one block per feature row (g, i) of the "self" side; other side has `n_other` groups.
 //   dh[e] = sum_o dl(g,o) * other_unit[o, i, e];  df = (dh - h * <h,dh>) * inv_norm
-// dl is indexed dl[g*sg + o*so] so the same kernel serves images (sg=C, so=1) and classes (sg=1, so=C).
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, int64_t sg, int64_t so,
-                                                       const float* __restrict__ self_unit,
-                                                       const float* __restrict__ self_inv,
-                                                       const float* __restrict__ other_unit, float* df,
-                                                       int n_other, int K, int e) {
+// Blocks [0, B*K) are the image rows (dl[g*C + o], o = class), blocks [B*K, B*K + C*K) the class rows
+// (dl[o*C + g], o = image): both sides in ONE launch.
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ ih,
+                                                       const float* __restrict__ ni, const float* __restrict__ th,
+                                                       const float* __restrict__ nt, float* d_img_f, float* d_text_f,
+                                                       int B, int C, int K, int e) {
   __shared__ float red[4];
-  const int row = blockIdx.x;            // g*K + i
+  const bool img = (int)blockIdx.x < B * K;
+  const int row = img ? blockIdx.x : blockIdx.x - B * K;            // g*K + i
   const int g = row / K, i = row % K;
+  const float* self_unit = img ? ih : th;
+  const float* self_inv = img ? ni : nt;
+  const float* other_unit = img ? th : ih;
+  float* df = img ? d_img_f : d_text_f;
+  const int n_other = img ? C : B;
+  const int64_t sg = img ? C : 1, so = img ? 1 : C;
   const float* h = self_unit + (int64_t)row * e;
   float dot = 0.f;
   // e <= 4 * 256 handled in registers
@@ -333,18 +355,15 @@ extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const i
   float* nt = ni + (int64_t)B * K;
   float* dl = nt + (int64_t)C * K;
   float* lb = dl + (int64_t)B * C;
-  hipLaunchKernelGGL(head_normalize_kernel, dim3(B * K), dim3(256), 0, s, img_f, ih, ni, B * K, e);
-  hipLaunchKernelGGL(head_normalize_kernel, dim3(C * K), dim3(256), 0, s, text_f, th, nt, C * K, e);
-  hipLaunchKernelGGL(head_logits_kernel, dim3(C, B), dim3(256), 0, s, ih, th, logits, C, K * e,
+  hipLaunchKernelGGL(head_normalize_kernel, dim3(B * K + C * K), dim3(256), 0, s, img_f, ih, ni, B * K, text_f, th, nt, e);
+  hipLaunchKernelGGL(head_logits_kernel, dim3((C + HEAD_CPB - 1) / HEAD_CPB, B), dim3(256), 0, s, ih, th, logits, C, K * e,
                      scale_exp / (float)K);
   if (label) {
     const float gmul = scale_exp / ((float)K * (float)B);
     hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
     hipLaunchKernelGGL(head_loss_mean_kernel, dim3(1), dim3(64), 0, s, lb, loss, B);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K), dim3(256), 0, s, dl, (int64_t)C, (int64_t)1, ih, ni, th,
-                       d_img_f, C, K, e);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(C * K), dim3(256), 0, s, dl, (int64_t)1, (int64_t)C, th, nt, ih,
-                       d_text_f, B, K, e);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K + C * K), dim3(256), 0, s, dl, ih, ni, th, nt, d_img_f, d_text_f,
+                       B, C, K, e);
   }
   return rpo_launch_status();
 }
