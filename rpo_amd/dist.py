@@ -68,7 +68,10 @@ class GradSync:
 
     def barrier(self) -> None:
         if self.enabled:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[self.local_rank])      # pins the barrier's collective to this rank's GPU
+            else:
+                dist.barrier()
 
     def close(self) -> None:
         if self.enabled and dist.is_initialized():
