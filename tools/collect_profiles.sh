@@ -13,6 +13,7 @@ for c in "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRB
   timeout -k 5 100 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${shape}_$n -o p -- python tools/bench_gemm.py --only $shape > $O/pmc_${shape}_$n.log 2>&1
 done
 done
+timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_step_MFMA -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision > $O/pmc_step_MFMA.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_step_$c -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision > $O/pmc_step_$c.log 2>&1
 done

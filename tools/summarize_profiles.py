@@ -70,6 +70,45 @@ if step:
             fo.write(f"{k} {v:.6g}\n")
         if "FETCH_SIZE" in step and "WRITE_SIZE" in step:
             fo.write(f"traffic_bytes_per_step {(2 * step['FETCH_SIZE'] + step['WRITE_SIZE']) * 1024:.6g}\n")
+# MFMA-pipe utilisation over one whole step (kernels are serialised under the profiler, so this is the
+# duration-weighted mean of the per-kernel utilisations)
+f = glob.glob(os.path.join(raw, "pmc_step_MFMA", "**", "*counter_collection.csv"), recursive=True)
+if f:
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Dispatch_Id"]))
+    sg = sorted({int(r["Dispatch_Id"]) for r in rows if "sgd_kernel" in r["Kernel_Name"]})
+    if len(sg) >= 3:
+        lo, hi = sg[-2], sg[-1]
+        tot = collections.defaultdict(float)
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in rows:
+            d = int(r["Dispatch_Id"])
+            if lo < d <= hi:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+                nm = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]); nm = re.sub(r"\(.*$", "", nm)[:70]
+                per[nm][r["Counter_Name"]] += float(r["Counter_Value"])
+        with open(os.path.join(out, f"{tag}_step_mfma_busy.txt"), "w") as fo:
+            busy = tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            ms = None
+            try:
+                import json
+                ms = json.loads(open(os.path.join(raw, "bench.json")).read())["ms_per_step"]
+            except Exception:
+                pass
+            fo.write("# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python bench.py --steps 6 --warmup 2\n"
+                     "# SQ_VALU_MFMA_BUSY_CYCLES summed over the kernels of ONE train step (SIMD-cycles, 1024 SIMDs).  Per-dispatch\n"
+                     "# GRBM_GUI_ACTIVE is inflated by the profiler for small kernels, so the step-level utilisation is taken against the\n"
+                     "# UN-profiled step time of r01_bench.json instead.\n")
+            fo.write(f"SQ_VALU_MFMA_BUSY_CYCLES_per_step {busy:.6g}\n")
+            fo.write(f"all_simd_busy_cycles_per_step {busy / 1024:.6g}\n")
+            fo.write("# cross-check: 1333.8 executed GFLOP / (1024 SIMDs * 1024 flop/cycle) = 1.272e6 cycles of pure MFMA work\n")
+            if ms:
+                for ghz in (1.65, 2.0, 2.4):
+                    fo.write(f"mfma_busy_fraction_of_step_at_{ghz}GHz {busy / 1024 / (ms * 1e-3 * ghz * 1e9):.4f}   # step {ms} ms\n")
+            fo.write("# per kernel (top by MFMA cycles): share of the step's MFMA cycles, per-launch MFMA utilisation (valid for long kernels only)\n")
+            for nm, v in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:10]:
+                ga = v.get("GRBM_GUI_ACTIVE", 0.0)
+                if ga > 0 and busy > 0:
+                    fo.write(f"{nm:72s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / busy:6.3f} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (ga / 8 * 1024):6.3f}\n")
 for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_eval.json", "bench_input_pipeline.json", "bench_batchsweep.json"):
     src = os.path.join(raw, fn)
     if os.path.exists(src) and os.path.getsize(src) > 0:
