@@ -240,10 +240,11 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     assert np.isfinite(d["config"]["final_loss"])
 
 
-@pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1)])
+@pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1), (4, 300, 2)])
 def test_edge_shapes_against_oracle_f32(K, n_cls, B):
     """K = 1 (reference asserts K >= 1), a class count that is not 19, the largest K that still fits the
-    context next to the longest prompt (len 24 -> K = 53), batch 1."""
+    context next to the longest prompt (len 24 -> K = 53), batch 1, and a class count beyond one 256-thread pass of
+    the head kernels (the reference's ImageNet configs have 500 / 1000 classes)."""
     from oracle.rpo_oracle import OracleRPO
     from rpo_amd.config import vit_b16
     from rpo_amd.custom_clip import CustomCLIP
