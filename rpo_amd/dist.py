@@ -27,12 +27,17 @@ class GradSync:
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # Test hooks for boxes with fewer GPUs than ranks: RPO_ALL_RANKS_ON_GPU0=1 puts every rank on cuda:0 and
+        # RPO_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the N-rank control flow
+        # (sharding, collectives, barriers, max-over-ranks timing) is then exercised end to end on one GPU.
+        if os.environ.get("RPO_ALL_RANKS_ON_GPU0") == "1":
+            self.local_rank = 0
         # RPO_FORCE_DIST=1 runs the collective path even with one rank (exercises RCCL init / all-reduce /
         # barrier on a single-GPU box; the numbers are unchanged: sum over one rank, scale 1)
         self.enabled = self.world_size > 1 or os.environ.get("RPO_FORCE_DIST") == "1"
         if self.enabled and init and not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("RPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
