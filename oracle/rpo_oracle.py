@@ -266,11 +266,12 @@ def cosine_lr_with_constant_warmup(base_lr: float, epoch: int, max_epoch: int,
     wrapping CosineAnnealingLR(T_max=max_epoch)
     (configs/trainers/RPO/main_K24.yaml:15-22; the scheduler code is in the
     un-vendored Dassl -- semantics restated from its published source:
-    epochs < warmup use the constant LR; afterwards the cosine successor is
-    evaluated at the *global* epoch index)."""
+    epochs < warmup use the constant LR; the wrapper's step() forwards to the
+    successor only once last_epoch >= warmup_epoch, so the cosine successor is
+    evaluated at epoch - warmup_epoch, not at the global epoch index)."""
     if epoch < warmup_epoch:
         return warmup_lr
-    return 0.5 * base_lr * (1.0 + math.cos(math.pi * epoch / max_epoch))
+    return 0.5 * base_lr * (1.0 + math.cos(math.pi * (epoch - warmup_epoch) / max_epoch))
 
 
 def train_steps(model: OracleRPO, opt: OracleSGD, batches) -> List[float]:

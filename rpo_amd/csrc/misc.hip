@@ -156,11 +156,15 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ 
   float s = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) s += expf(z[c] - m);
   s = block_sum(s, red);
-  const int lb = (int)label[b];
+  // F.cross_entropy (trainers/rpo.py:230) raises on an out-of-range target; a kernel cannot, so it neither reads
+  // out of bounds nor returns a plausible number: the loss becomes NaN (hosts validate labels they can see)
+  const int64_t lb64 = label[b];
+  const bool lb_ok = lb64 >= 0 && lb64 < C;
+  const int lb = lb_ok ? (int)lb64 : -1;
   const float inv = 1.0f / s;
   for (int c = threadIdx.x; c < C; c += 256)
     dl[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul;
-  if (threadIdx.x == 0) loss_b[b] = (m + logf(s)) - z[lb];
+  if (threadIdx.x == 0) loss_b[b] = lb_ok ? (m + logf(s)) - z[lb] : __builtin_nanf("");
 }
 
 __global__ void head_loss_mean_kernel(const float* __restrict__ loss_b, float* loss, int B) {

@@ -35,6 +35,8 @@ class GradSync:
         # RPO_FORCE_DIST=1 runs the collective path even with one rank (exercises RCCL init / all-reduce /
         # barrier on a single-GPU box; the numbers are unchanged: sum over one rank, scale 1)
         self.enabled = self.world_size > 1 or os.environ.get("RPO_FORCE_DIST") == "1"
+        if torch.cuda.is_available() and torch.cuda.device_count() > self.local_rank:
+            torch.cuda.set_device(self.local_rank)              # every backend: kernels launch on the current device
         if self.enabled and init and not dist.is_initialized():
             if backend is None:
                 backend = os.environ.get("RPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -42,6 +44,11 @@ class GradSync:
                 torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    def _pg(self) -> None:
+        if not dist.is_initialized():
+            raise RuntimeError(f"WORLD_SIZE={self.world_size} but no process group is initialised: construct "
+                               "GradSync() (init=True) or call torch.distributed.init_process_group first")
 
     @property
     def grad_scale(self) -> float:
@@ -57,22 +64,26 @@ class GradSync:
 
     def all_reduce_sum(self, flat: torch.Tensor) -> torch.Tensor:
         if self.enabled:
+            self._pg()
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.enabled:
+            self._pg()
             dist.broadcast(t, src=src)
         return t
 
     def max_over_ranks(self, value: float, device) -> float:
         t = torch.tensor([value], dtype=torch.float64, device=device)
         if self.enabled:
+            self._pg()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def barrier(self) -> None:
         if self.enabled:
+            self._pg()
             if dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[self.local_rank])      # pins the barrier's collective to this rank's GPU
             else:

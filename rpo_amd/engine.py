@@ -59,6 +59,9 @@ class Engine:
         if not torch.cuda.is_available():
             raise RuntimeError("rpo_amd.Engine needs a HIP device; there is no CPU path")
         ops.version()                                   # loads the library or raises
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.dev, self.act = cfg, device, act_dtype
         self.max_batch = max_batch
         self.kmult = 64 if act_dtype == torch.bfloat16 else 32
@@ -69,8 +72,9 @@ class Engine:
         self.Lmax = int(self.len_np.max())
         self.len_i32 = torch.tensor(self.len_np, dtype=torch.int32, device=device)
         self.logit_scale_exp = float(np.exp(np.float32(state_dict["logit_scale"])))
-        self._pack(state_dict, tokens)
-        self._alloc()
+        with torch.cuda.device(device):                 # the convert kernels of _pack launch on the current device
+            self._pack(state_dict, tokens)
+            self._alloc()
         self.text_cache_ready = False
         self.text_f_version = -1        # prompts version the cached eval text features belong to
         self.params_version = 0         # bumped by whoever changes the prompts (optimiser step, load)
@@ -387,6 +391,10 @@ class Engine:
     def _check(self, image: torch.Tensor) -> int:
         cfg = self.cfg
         assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous()
+        # kernels are enqueued on the CURRENT device's streams (ops._stream): refuse a foreign device instead of
+        # launching GPU-0 kernels on GPU-1 pointers
+        assert image.device == self.dev and torch.cuda.current_device() == self.dev.index, \
+            f"engine lives on {self.dev}: make it the current device and pass tensors that live there"
         B = image.shape[0]
         assert 1 <= B <= self.max_batch and tuple(image.shape[1:]) == (3, cfg.image_size, cfg.image_size)
         if not self.text_cache_ready:

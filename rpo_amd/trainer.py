@@ -39,12 +39,16 @@ class OptimConfig:
 
 
 def lr_at_epoch(oc: OptimConfig, epoch: int) -> float:
-    """LR in force during 0-based ``epoch``: constant warm-up, then cosine annealing evaluated
-    at the global epoch index (Dassl ConstantWarmupScheduler over CosineAnnealingLR(T_max=max_epoch))."""
-    if epoch < oc.warmup_epoch and oc.warmup_type == "constant":
+    """LR in force during 0-based ``epoch`` under Dassl's ConstantWarmupScheduler wrapping
+    CosineAnnealingLR(T_max=max_epoch) (`build_lr_scheduler`, trainers/rpo.py:275): the warm-up wrapper does NOT
+    step its successor while it warms up, so the cosine starts at its own epoch 0 when the warm-up ends --
+    epoch e >= warmup runs at cos(pi * (e - warmup) / T), i.e. epoch 1 of the yaml's schedule runs at the full
+    0.01 (pinned against a re-creation driven by torch's CosineAnnealingLR in tests/test_host_logic.py)."""
+    warm = oc.warmup_epoch if oc.warmup_type == "constant" else 0
+    if epoch < warm:
         return oc.warmup_cons_lr
     if oc.lr_scheduler == "cosine":
-        return 0.5 * oc.lr * (1.0 + math.cos(math.pi * epoch / oc.max_epoch))
+        return 0.5 * oc.lr * (1.0 + math.cos(math.pi * (epoch - warm) / oc.max_epoch))
     return oc.lr
 
 
@@ -56,15 +60,24 @@ class RPO:
         self.cfg = cfg
         self.optim_cfg = optim or OptimConfig()
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.batch_size = batch_size
         self.num_batches = num_batches
-        self.sync = sync or GradSync(init=False)
+        # default: joins (or creates) the process group when launched under torchrun; a lone process stays local
+        self.sync = sync or GradSync()
         self.use_graph = use_graph
         self.epoch = 0
         self.batch_idx = 0
         self._steps = 0
         self._graph = None
-        self.build_model(state_dict, tokens, act_dtype, prompts)
+        self.best_result = -float("inf")
+        # trainers/rpo.py:287-288 turns on autograd anomaly detection ("nan detector"); there is no autograd graph
+        # here, so the counterpart is a scan of loss + prompt gradients after the step (RPO_DETECT_ANOMALY=1 or
+        # detect_anomaly=True; costs one D2H sync per step, so it is off in timed runs)
+        self.detect_anomaly = os.environ.get("RPO_DETECT_ANOMALY") == "1"
+        with torch.cuda.device(self.device):
+            self.build_model(state_dict, tokens, act_dtype, prompts)
 
     # trainers/rpo.py:240-288
     def build_model(self, state_dict, tokens, act_dtype, prompts) -> None:
@@ -97,7 +110,15 @@ class RPO:
             img = self.transform(True)(img, out=self._image if len(img) == self.batch_size else None)
         else:
             img = img.to(self.device, dtype=torch.float32, non_blocking=True)
-        return img, torch.as_tensor(batch["label"]).to(self.device, dtype=torch.int64, non_blocking=True)
+        label = torch.as_tensor(batch["label"])
+        if not label.is_cuda:
+            # F.cross_entropy (trainers/rpo.py:230) raises on an out-of-range target; the head kernel would read out
+            # of bounds instead, so validate where it is free (labels arrive on the host)
+            lo, hi = int(label.min()), int(label.max())
+            if lo < 0 or hi >= self.cfg.n_cls:
+                raise IndexError(f"Target {hi if hi >= self.cfg.n_cls else lo} is out of bounds "
+                                 f"(n_cls = {self.cfg.n_cls}; labels must be renumbered after the base/new split)")
+        return img, label.to(self.device, dtype=torch.int64, non_blocking=True)
 
     def _capture(self) -> None:
         """Capture the step as FIVE HIP graphs on two streams instead of one graph with parallel
@@ -146,9 +167,12 @@ class RPO:
 
     def forward_backward(self, batch) -> Dict[str, float]:
         """trainers/rpo.py:290-316."""
-        image, label = self.parse_batch_train(batch)
-        loss = self.step_async(image, label)
-        summary = {"loss": float(loss.item())}                  # D2H sync, as the reference (:311)
+        with torch.cuda.device(self.device):
+            image, label = self.parse_batch_train(batch)
+            loss = self.step_async(image, label)
+            summary = {"loss": float(loss.item())}              # D2H sync, as the reference (:311)
+            if self.detect_anomaly:
+                self.check_finite()
         if (self.batch_idx + 1) == self.num_batches:
             self.update_lr()
             self.batch_idx = 0
@@ -157,8 +181,10 @@ class RPO:
         return summary
 
     def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
-        """One optimisation step, nothing synchronised; returns the device loss scalar."""
+        """One optimisation step, nothing synchronised; returns the device loss scalar.  The caller's current
+        device must be this trainer's (kernels launch on the current device's streams)."""
         eng, oc = self.engine, self.optim_cfg
+        assert torch.cuda.current_device() == self.device.index, "set the trainer's device current (torch.cuda.set_device)"
         assert image.shape[0] == self.batch_size, "graph path needs the configured batch size"
         if image.data_ptr() != self._image.data_ptr():
             self._image.copy_(image, non_blocking=True)
@@ -181,27 +207,46 @@ class RPO:
         self.epoch += 1
         self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
 
+    def check_finite(self) -> None:
+        """NaN / Inf scan of the step's outputs (the reference's `set_detect_anomaly(True)`, trainers/rpo.py:288)."""
+        eng = self.engine
+        bad = [n for n, t in (("loss", eng.loss), ("logits", eng.logits[:self.batch_size]), ("grad text_prompt", eng.g_text),
+                              ("grad img_prompt", eng.g_img), ("prompts", eng.params)) if not bool(torch.isfinite(t).all())]
+        if bad:
+            raise FloatingPointError(f"non-finite values after step {self._steps}: {', '.join(bad)}")
+
     # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
     @torch.no_grad()
     def model_inference(self, image) -> torch.Tensor:
-        if isinstance(image, (list, tuple)):                    # decoded uint8 images: resize + center crop + normalize
-            image = self.transform(False)(image)
-        self.model.prompt_learner.eval()
-        try:
-            return self.model(image)
-        finally:
-            self.model.prompt_learner.train()
+        with torch.cuda.device(self.device):
+            if isinstance(image, (list, tuple)):                # decoded uint8 images: resize + center crop + normalize
+                image = self.transform(False)(image)
+            self.model.prompt_learner.eval()
+            try:
+                return self.model(image)
+            finally:
+                self.model.prompt_learner.train()
 
-    # -- checkpoints: Dassl layout <dir>/prompt_learner/model.pth.tar-<epoch> ----------------
-    def save_model(self, directory: str, epoch: Optional[int] = None) -> str:
+    # -- checkpoints: Dassl layout <dir>/prompt_learner/{model.pth.tar-<epoch>, model-best.pth.tar} ----------
+    def save_model(self, directory: str, epoch: Optional[int] = None, is_best: bool = False,
+                   val_result: Optional[float] = None) -> str:
+        """What Dassl's `TrainerBase.save_model` -> `save_checkpoint` leaves on disk and the reference's reader
+        (trainers/rpo.py:325-357) consumes: `state_dict` (the two prompt tensors), `epoch`, `optimizer`,
+        `scheduler`, `val_result`; `is_best` also writes `model-best.pth.tar`, the file `load_model` opens by
+        default (:333).  The optimiser entry is torch.optim.SGD's own state-dict layout, so a reference run can
+        resume from it."""
         epoch = self.epoch if epoch is None else epoch
-        path = os.path.join(directory, "prompt_learner")
-        os.makedirs(path, exist_ok=True)
-        fn = os.path.join(path, f"model.pth.tar-{epoch}")
-        sd = {k: v.detach().cpu().clone() for k, v in self.model.prompt_learner.state_dict().items()}
-        torch.save({"state_dict": sd, "epoch": epoch, "momentum": self.engine.mom.cpu(),
-                    "steps": self._steps}, fn)
-        return fn
+        ck = checkpoint_dict(self.model.prompt_learner.state_dict(), epoch, self.engine.mom, self.optim_cfg,
+                             self.lr, self._steps, self.cfg.K * self.cfg.d_t, val_result)
+        return write_checkpoint(directory, ck, epoch, is_best)
+
+    def after_epoch_eval(self, directory: str, val_result: float) -> bool:
+        """Dassl's `after_epoch` bookkeeping for `model-best`: keep the checkpoint with the best validation result."""
+        is_best = val_result > self.best_result
+        if is_best:
+            self.best_result = val_result
+            self.save_model(directory, is_best=True, val_result=val_result)
+        return is_best
 
     def load_model(self, directory: str, epoch: Optional[int] = None) -> None:
         """trainers/rpo.py:325-357."""
@@ -212,17 +257,64 @@ class RPO:
         model_path = os.path.join(directory, "prompt_learner", model_file)
         if not os.path.exists(model_path):
             raise FileNotFoundError(f'Model not found at "{model_path}"')
-        ck = torch.load(model_path, map_location="cpu", weights_only=False)
-        sd = ck["state_dict"]
-        for k in ("token_prefix", "token_suffix"):
+        # tensors, numbers and plain containers only (ours and Dassl's): no arbitrary unpickling
+        ck = torch.load(model_path, map_location="cpu", weights_only=True)
+        sd = dict(ck["state_dict"])
+        for k in ("token_prefix", "token_suffix"):              # :348-352
             sd.pop(k, None)
-        with torch.no_grad():
+        print(f'Loading weights to prompt_learner from "{model_path}" (epoch = {ck["epoch"]})')
+        with torch.no_grad():                                   # load_state_dict(strict=False), :357
             for name, p in self.model.prompt_learner.named_parameters():
                 if name in sd:
                     p.copy_(sd[name].to(p.dtype))
-        if "momentum" in ck:
-            self.engine.mom.copy_(ck["momentum"])
-            self._steps = int(ck.get("steps", 1))
+        mom = _momentum_from_optimizer_state(ck.get("optimizer"), self.engine.mom.numel())
+        if mom is not None:
+            self.engine.mom.copy_(mom)
+            self._steps = max(1, int(ck.get("steps", 1)))
         self.engine.params_version += 1
         self.epoch = int(ck.get("epoch", 0))
         self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+
+
+def checkpoint_dict(prompt_state, epoch: int, momentum: Optional[torch.Tensor], oc: OptimConfig, lr: float,
+                    steps: int, n_text: int, val_result: Optional[float] = None) -> dict:
+    """The dict Dassl's `save_checkpoint` pickles (keys `state_dict`, `epoch`, `optimizer`, `scheduler`,
+    `val_result`); `optimizer` in torch.optim.SGD.state_dict() layout (param 0 = text_prompt, 1 = img_prompt)."""
+    sd = {k: v.detach().cpu().clone() for k, v in prompt_state.items()}
+    state = {}
+    if momentum is not None and steps > 0:
+        m = momentum.detach().cpu()
+        state = {0: {"momentum_buffer": m[:n_text].reshape(sd["text_prompt"].shape).clone()},
+                 1: {"momentum_buffer": m[n_text:].reshape(sd["img_prompt"].shape).clone()}}
+    group = {"lr": lr, "momentum": oc.momentum, "dampening": 0, "weight_decay": oc.weight_decay, "nesterov": False,
+             "maximize": False, "foreach": None, "differentiable": False, "fused": None, "initial_lr": oc.lr,
+             "params": [0, 1]}
+    return {"state_dict": sd, "epoch": int(epoch), "optimizer": {"state": state, "param_groups": [group]},
+            "scheduler": {"last_epoch": int(epoch)}, "val_result": val_result, "steps": int(steps)}
+
+
+def write_checkpoint(directory: str, ck: dict, epoch: int, is_best: bool = False) -> str:
+    path = os.path.join(directory, "prompt_learner")
+    os.makedirs(path, exist_ok=True)
+    fn = os.path.join(path, f"model.pth.tar-{epoch}")
+    torch.save(ck, fn)
+    with open(os.path.join(path, "checkpoint"), "w") as f:      # Dassl's pointer file to the newest checkpoint
+        f.write(os.path.basename(fn) + "\n")
+    if is_best:
+        import shutil
+        shutil.copyfile(fn, os.path.join(path, "model-best.pth.tar"))
+    return fn
+
+
+def _momentum_from_optimizer_state(opt_state, numel: int) -> Optional[torch.Tensor]:
+    if not opt_state or not opt_state.get("state"):
+        return None
+    st = opt_state["state"]
+    try:
+        bufs = [st[i]["momentum_buffer"] for i in (0, 1)]
+    except (KeyError, TypeError):
+        return None
+    if any(b is None for b in bufs):
+        return None
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    return flat if flat.numel() == numel else None

@@ -16,6 +16,7 @@ CASES = {
     "d1_k4_b2": (1, 4, 2, np.log(100.0)),
     "d2_k8_b3": (2, 8, 3, np.log(100.0)),
     "d2_k24_b2_init": (2, 24, 2, np.log(1 / 0.07)),
+    "d2_k16_b2": (2, 16, 2, np.log(100.0)),
     "d2_k48_b2": (2, 48, 2, np.log(100.0)),
     "d12_k24_b4": (12, 24, 4, np.log(100.0)),
 }

@@ -8,6 +8,8 @@ updated prompts and 1e-3 relative-to-max on gradients (measured ~1e-5).
 The bf16 throughput mode cannot meet 1e-3 at logit scale 100 (SURVEY.md section 7);
 it is asserted at a documented looser bound and its measured error is printed.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,8 +20,8 @@ from helpers import CASES, load_golden, workload  # noqa: E402
 from rpo_amd import synth  # noqa: E402
 
 TOL_F32 = 1e-3
-BF16_LOGIT_ATOL = 0.35         # logits are O(1..8) at scale 100
-BF16_GRAD_REL = 0.12           # relative to max |grad|
+BF16_LOGIT_ATOL = 0.12         # logits are O(1..8) at scale 100; measured <= 0.06 (printed by the test)
+BF16_GRAD_REL = 0.05           # relative to max |grad|; measured 2.0-2.3 %
 
 
 def _model(tag, act, max_batch=None):
@@ -177,7 +179,7 @@ def test_checkpoint_roundtrip(tmp_path):
     tr = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=(tp, ip))
     tr.forward_backward({"img": torch.from_numpy(image), "label": torch.from_numpy(label)})
     fn = tr.save_model(str(tmp_path), epoch=3)
-    ck = torch.load(fn, map_location="cpu", weights_only=False)
+    ck = torch.load(fn, map_location="cpu", weights_only=True)
     assert set(ck["state_dict"]) == {"text_prompt", "img_prompt"} and ck["epoch"] == 3
     tr2 = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=(tp, ip))
     tr2.load_model(str(tmp_path), epoch=3)
@@ -295,17 +297,26 @@ def test_edge_shapes_against_oracle_f32(K, n_cls, B):
     np.testing.assert_allclose(m(torch.from_numpy(image).cuda()).cpu().numpy(), out.logits.detach().numpy(), atol=TOL_F32)
 
 
-@pytest.mark.parametrize("act", [torch.float32, torch.bfloat16])
-def test_full_size_properties(act):
-    """BASELINE.json configs[1] at full size (12 layers, K=24, B=32), where the CPU oracle is too slow to be the
-    checker: size-independent properties of the step instead."""
-    from rpo_amd.config import vit_b16
+FULL_SIZE = [("ViT-B/16", 24, 32, torch.float32), ("ViT-B/16", 24, 32, torch.bfloat16),
+             ("ViT-B/16", 4, 32, torch.bfloat16), ("ViT-B/16", 8, 32, torch.bfloat16),
+             ("ViT-B/16", 16, 32, torch.float32), ("ViT-B/16", 16, 32, torch.bfloat16),
+             ("ViT-B/16", 48, 32, torch.bfloat16),
+             ("ViT-L/14", 24, 16, torch.float32), ("ViT-L/14", 24, 16, torch.bfloat16)]
+
+
+@pytest.mark.parametrize("model,K,B,act", FULL_SIZE, ids=lambda v: str(v).replace("torch.", ""))
+def test_full_size_properties(model, K, B, act):
+    """BASELINE.json configs[1], [3] and every point of the configs[4] K sweep at FULL size (all layers, the bench's
+    batch), where the CPU oracle is too slow to be the checker: size-independent properties of the step, and the
+    throughput mode against the exact-f32 mode of the same engine (which tests/ pin to the reference at small depth).
+    These are the shapes bench.py runs, i.e. the tile selections (256x256 ping-pong in-proj at M = 7072 / 4496,
+    128x128 c_fc, 64x128 out-proj ...) are compared at model level here."""
+    from rpo_amd.config import vit_b16, vit_l14
     from rpo_amd.trainer import RPO
-    cfg = vit_b16()
+    cfg = (vit_b16 if model == "ViT-B/16" else vit_l14)(K=K)
     toks = synth.oxford_pets_base_tokens()
     sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
     tp, ip = synth.prompts(cfg, sd, seed=7)
-    B = 32
     img = torch.from_numpy(synth.images(cfg, B)).cuda()
     lab = torch.from_numpy(synth.labels(cfg, B)).cuda()
     tr = RPO(cfg, sd, toks, None, "cuda:0", act, batch_size=B, prompts=(tp, ip))
@@ -324,10 +335,11 @@ def test_full_size_properties(act):
     # (3) loss = mean CE of those logits (fp32 head): recompute on the host
     ce = torch.nn.functional.cross_entropy(lg0.double().cpu(), lab.cpu()).item()
     assert abs(ce - l0.item()) <= 1e-5 * max(1.0, abs(ce))
-    # (4) linearity of mean-CE gradients in the batch: g(32) == (g(first 16) + g(last 16)) / 2
-    eng.forward_backward(img[:16].contiguous(), lab[:16].contiguous()); torch.cuda.synchronize()
+    # (4) linearity of mean-CE gradients in the batch: g(B) == (g(first half) + g(second half)) / 2
+    h = B // 2
+    eng.forward_backward(img[:h].contiguous(), lab[:h].contiguous()); torch.cuda.synchronize()
     ga = eng.grads.clone()
-    eng.forward_backward(img[16:].contiguous(), lab[16:].contiguous()); torch.cuda.synchronize()
+    eng.forward_backward(img[h:].contiguous(), lab[h:].contiguous()); torch.cuda.synchronize()
     gb = eng.grads.clone()
     rel = ((ga + gb) / 2 - g0).abs().max().item() / g0.abs().max().item()
     assert rel <= (2e-5 if act == torch.float32 else 2e-2), rel
@@ -336,6 +348,150 @@ def test_full_size_properties(act):
     loss_graph = tr.forward_backward({"img": img, "label": lab})["loss"]
     assert loss_graph == l0.item()
     assert not torch.equal(eng.params, before)
+    # (6) throughput mode vs the exact-f32 mode at this size (f32 run first in the parametrisation caches its result)
+    key = (model, K, B)
+    if act == torch.float32:
+        _F32_FULL[key] = (lg0.cpu(), g0.cpu())
+    elif key in _F32_FULL:
+        lf, gf = _F32_FULL[key]
+        le = (lg0.cpu() - lf).abs().max().item()
+        nt = cfg.K * cfg.d_t
+        rt = (g0.cpu()[:nt] - gf[:nt]).abs().max().item() / gf[:nt].abs().max().item()
+        ri = (g0.cpu()[nt:] - gf[nt:]).abs().max().item() / gf[nt:].abs().max().item()
+        print(f"[full size {model} K={K} B={B} {act}] vs f32 mode: logits err {le:.3e} g_text rel {rt:.3e} g_img rel {ri:.3e}")
+        assert le <= BF16_LOGIT_ATOL and rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL
+
+
+_F32_FULL = {}
+
+
+def test_two_ranks_equal_one_rank_global_batch(tmp_path):
+    """SURVEY.md section 8e's own correctness test on the HIP path: 2 ranks x B/2 images (both on this box's one GPU,
+    gloo instead of RCCL, which refuses two ranks on one device) for two SGD steps must leave the prompts a 1-rank
+    run on the global batch leaves, to summation-order noise.  Rank 1 starts from perturbed prompts, so the
+    start-up broadcast is covered too."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dp_equiv_worker.py")
+    G, steps = 4, 2
+    outs = {}
+    for world in (1, 2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, RPO_DIST_BACKEND="gloo", RPO_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = str(tmp_path / f"w{world}.npz")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), worker, out, str(G), str(steps), "f32"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = dict(np.load(out))
+    assert int(outs[2]["world"]) == 2
+    a, b = outs[1]["params"], outs[2]["params"]
+    assert np.abs(a - b).max() <= 1e-6, np.abs(a - b).max()
+    # each rank's loss is the mean over ITS shard: rank 0's differs from the global mean, the prompts do not
+    assert np.isfinite(outs[2]["losses"]).all()
+
+
+def test_reference_shaped_constructor_and_seeded_init():
+    """`CustomCLIP(cfg, classnames, prompt, clipmodel)` exactly as trainers/rpo.py:255 calls it; the prompts it draws
+    under torch.manual_seed are the reference's own (G7 fixture: the REAL PromptLearner.initialization_token under the
+    same seed), and so are the logits they give."""
+    import types
+    from rpo_amd.config import OXFORD_PETS_BASE_CLASSES, PROMPT_TEMPLATE, vit_b16
+    from rpo_amd.custom_clip import CustomCLIP
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_init_seed3_d1_k4.npz")))
+    cfg = vit_b16(layers_v=1, layers_t=1, K=4)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+
+    class FakeCLIP:                                   # stands in for clip.model.CLIP: only .state_dict() is used
+        def state_dict(self):
+            return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+    ns = types.SimpleNamespace
+    rcfg = ns(TRAINER=ns(RPO=ns(K=4, PREC="fp32")), INPUT=ns(SIZE=(224, 224)))
+    torch.manual_seed(int(g["seed"]))
+    m = CustomCLIP(rcfg, list(OXFORD_PETS_BASE_CLASSES), PROMPT_TEMPLATE, FakeCLIP())
+    assert m.engine.act == torch.float32 and m.cfg == cfg
+    assert np.abs(m.prompt_learner.text_prompt.detach().cpu().numpy() - g["text_prompt"]).max() <= 1e-7
+    assert np.abs(m.prompt_learner.img_prompt.detach().cpu().numpy() - g["img_prompt"]).max() <= 1e-7
+    m.prompt_learner.eval()
+    logits = m(torch.from_numpy(synth.images(cfg, 2)).cuda()).cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() <= TOL_F32
+    # a tokenizer callable replaces the bundled table
+    toks = synth.oxford_pets_base_tokens()
+    table = {PROMPT_TEMPLATE.replace("_", c): toks[i:i + 1] for i, c in enumerate(OXFORD_PETS_BASE_CLASSES)}
+    m2 = CustomCLIP(rcfg, list(OXFORD_PETS_BASE_CLASSES)[:5], PROMPT_TEMPLATE, FakeCLIP(), tokenize=lambda t: table[t])
+    assert m2.cfg.n_cls == 5 and m2.len_prompts.tolist() == [10, 10, 14, 11, 8]
+    with pytest.raises(ValueError):
+        CustomCLIP(rcfg, ["cat", "dog"], PROMPT_TEMPLATE, FakeCLIP())
+    with pytest.raises(IndexError):
+        m2.prompt_learner.train()
+        m2(torch.from_numpy(synth.images(cfg, 2)).cuda(), torch.tensor([0, 7]))
+
+
+def test_reference_checkpoint_fixture_loads(tmp_path):
+    """Row f2: the committed checkpoint directory was written by the reference side (tools/make_golden.py G8: the REAL
+    prompt_learner.state_dict() after one torch.optim.SGD step, in the `prompt_learner/model-best.pth.tar` +
+    `model.pth.tar-2` layout trainers/rpo.py:325-357 reads, with the token_prefix / token_suffix keys it drops).
+    Loading it must give the reference's prompts bit-for-bit, its eval logits and its momentum buffers; what
+    `save_model(is_best=True)` writes back must satisfy the same reader contract."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.trainer import RPO
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = dict(np.load(os.path.join(gold, "ref_ckpt_d1_k4.npz")))
+    cfg = vit_b16(layers_v=1, layers_t=1, K=4)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    image = torch.from_numpy(synth.images(cfg, 2)).cuda()
+    for epoch in (None, 2):                           # default = model-best (:333)
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=synth.prompts(cfg, sd, seed=99))
+        tr.load_model(os.path.join(gold, "ckpt_d1_k4"), epoch=epoch)
+        assert np.array_equal(tr.model.prompt_learner.text_prompt.detach().cpu().numpy(), g["text_prompt"])
+        assert np.array_equal(tr.model.prompt_learner.img_prompt.detach().cpu().numpy(), g["img_prompt"])
+        assert tr.epoch == 2
+        nt = cfg.K * cfg.d_t
+        assert np.array_equal(tr.engine.mom[:nt].cpu().numpy().reshape(g["momentum_text"].shape), g["momentum_text"])
+        assert np.array_equal(tr.engine.mom[nt:].cpu().numpy().reshape(g["momentum_img"].shape), g["momentum_img"])
+        assert np.abs(tr.model_inference(image).cpu().numpy() - g["logits"]).max() <= TOL_F32
+    with pytest.raises(FileNotFoundError):
+        tr.load_model(os.path.join(gold, "ckpt_d1_k4"), epoch=7)
+    # writer: model-best + model.pth.tar-N, readable without arbitrary unpickling, reader-contract keys
+    fn = tr.save_model(str(tmp_path), epoch=5, is_best=True, val_result=71.0)
+    best = os.path.join(str(tmp_path), "prompt_learner", "model-best.pth.tar")
+    assert os.path.exists(best) and fn.endswith("model.pth.tar-5")
+    ck = torch.load(best, map_location="cpu", weights_only=True)
+    assert {"state_dict", "epoch", "optimizer", "scheduler", "val_result"} <= set(ck) and ck["epoch"] == 5
+    assert set(ck["state_dict"]) == {"text_prompt", "img_prompt"}
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros_like(ck["state_dict"][k])) for k in ("text_prompt", "img_prompt")],
+                          lr=0.1, momentum=0.9)
+    opt.load_state_dict(ck["optimizer"])              # torch.optim.SGD's own layout: a reference run can resume from it
+    assert torch.equal(opt.state_dict()["state"][0]["momentum_buffer"], torch.from_numpy(g["momentum_text"]))
+    assert tr.after_epoch_eval(str(tmp_path), 80.0) and not tr.after_epoch_eval(str(tmp_path), 10.0)
+    assert torch.load(best, map_location="cpu", weights_only=True)["val_result"] == 80.0
+
+
+def test_anomaly_scan_and_bad_labels():
+    """trainers/rpo.py:287-288 (nan detector) and F.cross_entropy's target check (:230)."""
+    from rpo_amd.trainer import RPO
+    tag = "d1_k4_b2"
+    cfg, sd, toks, tp, ip, image, label = workload(tag)
+    tr = RPO(cfg, sd, toks, None, "cuda:0", torch.float32, batch_size=2, prompts=(tp, ip))
+    tr.detect_anomaly = True
+    tr.forward_backward({"img": torch.from_numpy(image), "label": torch.from_numpy(label)})      # finite: passes
+    with pytest.raises(IndexError):
+        tr.forward_backward({"img": torch.from_numpy(image), "label": torch.tensor([0, cfg.n_cls])})
+    bad = torch.from_numpy(image).clone()
+    bad[0, 0, 0, 0] = float("nan")
+    with pytest.raises(FloatingPointError):
+        tr.forward_backward({"img": bad, "label": torch.from_numpy(label)})
+    # a device-resident out-of-range label cannot raise from the kernel: the loss is NaN, not a plausible number
+    tr.detect_anomaly = False
+    tr.engine.forward_backward(torch.from_numpy(image).cuda(), torch.tensor([0, 400], device="cuda"))
+    assert torch.isnan(tr.engine.loss).all()
 
 
 @pytest.mark.gpu

@@ -9,6 +9,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -78,15 +79,118 @@ def test_product_never_imports_oracle():
             assert not any(m.split(".")[0] == "oracle" for m in mods), f"{fn} imports the oracle"
 
 
-def test_lr_schedule_matches_restated_dassl_semantics():
+class _ConstantWarmup(torch.optim.lr_scheduler.LRScheduler):
+    """Dassl's ConstantWarmupScheduler, re-created from its published semantics (Dassl.pytorch is not vendored:
+    dassl/optim/lr_scheduler.py `_BaseWarmupScheduler.step` forwards to the successor only once
+    last_epoch >= warmup_epoch, else does a plain scheduler step returning the constant LR)."""
+
+    def __init__(self, optimizer, successor, warmup_epoch, cons_lr):
+        self.successor, self.warmup_epoch, self.cons_lr = successor, warmup_epoch, cons_lr
+        super().__init__(optimizer)
+
+    def get_lr(self):
+        if self.last_epoch >= self.warmup_epoch:
+            return self.successor.get_last_lr()
+        return [self.cons_lr for _ in self.base_lrs]
+
+    def step(self, epoch=None):
+        if self.last_epoch >= self.warmup_epoch:
+            self.successor.step(epoch)
+            self._last_lr = self.successor.get_last_lr()
+        else:
+            super().step(epoch)
+
+
+@pytest.mark.parametrize("warmup,max_epoch,lr", [(1, 15, 0.01), (0, 15, 0.01), (3, 10, 0.002)])
+def test_lr_schedule_matches_torch_driven_dassl_recreation(warmup, max_epoch, lr):
+    """The product's closed form (and the oracle's) against torch's CosineAnnealingLR stepped by the re-created
+    Dassl warm-up wrapper, the way `TrainerX.update_lr` steps it once per epoch (trainers/rpo.py:313-314)."""
+    import warnings
     from oracle.rpo_oracle import cosine_lr_with_constant_warmup
     from rpo_amd.trainer import OptimConfig, lr_at_epoch
-    oc = OptimConfig()
-    assert lr_at_epoch(oc, 0) == 1e-5                       # main_K24.yaml:20-22
-    for ep in range(15):
-        assert lr_at_epoch(oc, ep) == cosine_lr_with_constant_warmup(0.01, ep, 15, 1, 1e-5)
-    assert math.isclose(lr_at_epoch(oc, 1), 0.5 * 0.01 * (1 + math.cos(math.pi / 15)))
-    assert lr_at_epoch(oc, 14) < lr_at_epoch(oc, 2)
+    oc = OptimConfig(lr=lr, max_epoch=max_epoch, warmup_epoch=warmup)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=lr)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        succ = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max_epoch)
+        sched = _ConstantWarmup(opt, succ, warmup, 1e-5) if warmup > 0 else succ
+        for ep in range(max_epoch):
+            want = opt.param_groups[0]["lr"]
+            assert math.isclose(lr_at_epoch(oc, ep), want, rel_tol=1e-9, abs_tol=1e-15), (ep, lr_at_epoch(oc, ep), want)
+            assert math.isclose(cosine_lr_with_constant_warmup(lr, ep, max_epoch, warmup, 1e-5), want,
+                                rel_tol=1e-9, abs_tol=1e-15)
+            opt.step()
+            sched.step()
+
+
+def test_lr_schedule_yaml_values():
+    from rpo_amd.trainer import OptimConfig, lr_at_epoch
+    oc = OptimConfig()                                      # main_K24.yaml:15-22
+    assert lr_at_epoch(oc, 0) == 1e-5
+    assert lr_at_epoch(oc, 1) == 0.01                       # the cosine starts when the warm-up ends
+    assert math.isclose(lr_at_epoch(oc, 14), 0.5 * 0.01 * (1 + math.cos(math.pi * 13 / 15)))   # 4.32e-4
+
+
+def test_checkpoint_writer_satisfies_the_reference_reader_contract(tmp_path):
+    """trainers/rpo.py:325-357 opens <dir>/prompt_learner/model-best.pth.tar (or model.pth.tar-<epoch>), reads
+    checkpoint["state_dict"] / ["epoch"], drops token_prefix / token_suffix and load_state_dict(strict=False)s the
+    rest into PromptLearner (parameters text_prompt [K, d_t], img_prompt [K, 768])."""
+    from rpo_amd.trainer import OptimConfig, checkpoint_dict, write_checkpoint, _momentum_from_optimizer_state
+    K, dt, dv = 4, 512, 768
+    state = {"text_prompt": torch.randn(K, dt), "img_prompt": torch.randn(K, dv)}
+    mom = torch.randn(K * dt + K * dv)
+    ck = checkpoint_dict(state, 7, mom, OptimConfig(), 0.005, 12, K * dt, val_result=55.5)
+    fn = write_checkpoint(str(tmp_path), ck, 7, is_best=True)
+    d = os.path.join(str(tmp_path), "prompt_learner")
+    assert sorted(os.listdir(d)) == ["checkpoint", "model-best.pth.tar", "model.pth.tar-7"]
+    assert open(os.path.join(d, "checkpoint")).read().strip() == "model.pth.tar-7" and fn.endswith("model.pth.tar-7")
+    for name in ("model-best.pth.tar", "model.pth.tar-7"):
+        got = torch.load(os.path.join(d, name), map_location="cpu", weights_only=True)
+        assert got["epoch"] == 7 and got["val_result"] == 55.5
+        assert set(got["state_dict"]) == {"text_prompt", "img_prompt"}
+
+        class PL(torch.nn.Module):                          # the reader's target module, shape-wise
+            def __init__(self):
+                super().__init__()
+                self.text_prompt = torch.nn.Parameter(torch.zeros(K, dt))
+                self.img_prompt = torch.nn.Parameter(torch.zeros(K, dv))
+        pl = PL()
+        missing = pl.load_state_dict(got["state_dict"], strict=False)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        assert torch.equal(pl.text_prompt.data, state["text_prompt"])
+        opt = torch.optim.SGD(pl.parameters(), lr=0.1, momentum=0.9)
+        opt.load_state_dict(got["optimizer"])
+        assert opt.param_groups[0]["lr"] == 0.005 and opt.param_groups[0]["weight_decay"] == 5e-4
+        assert torch.equal(_momentum_from_optimizer_state(got["optimizer"], mom.numel()), mom)
+    assert _momentum_from_optimizer_state({"state": {}, "param_groups": []}, 5) is None
+
+
+def test_committed_reference_checkpoint_fixture_layout():
+    """tests/golden/ckpt_d1_k4 (written by tools/make_golden.py from the reference's own modules) loads without
+    arbitrary unpickling and carries the keys the reader touches."""
+    d = os.path.join(ROOT, "tests", "golden", "ckpt_d1_k4", "prompt_learner")
+    for name in ("model-best.pth.tar", "model.pth.tar-2"):
+        ck = torch.load(os.path.join(d, name), map_location="cpu", weights_only=True)
+        assert ck["epoch"] == 2 and {"text_prompt", "img_prompt", "token_prefix", "token_suffix"} == set(ck["state_dict"])
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_d1_k4.npz")))
+    assert np.array_equal(ck["state_dict"]["text_prompt"].numpy(), g["text_prompt"])
+
+
+def test_config_from_state_dict_and_seeded_init_formula():
+    from rpo_amd import synth
+    from rpo_amd.config import vit_b16, vit_l14
+    from rpo_amd.custom_clip import config_from_state_dict, init_prompts
+    for c in (vit_b16(layers_v=2, layers_t=3, K=5), vit_l14(layers_v=1, layers_t=1)):
+        sd = synth.clip_state_dict(c, seed=0, token_rows=[49407])
+        assert config_from_state_dict(sd, c.K, c.n_cls) == c
+    # G7: the reference's own initialisation under torch.manual_seed(3)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_init_seed3_d1_k4.npz")))
+    c = vit_b16(layers_v=1, layers_t=1, K=4)
+    sd = synth.clip_state_dict(c, seed=0, logit_scale=float(np.log(100.0)))
+    torch.manual_seed(int(g["seed"]))
+    tp, ip = init_prompts(sd, 4, c.d_t, c.d_v)
+    assert np.abs(tp - g["text_prompt"]).max() <= 1e-7 and np.abs(ip - g["img_prompt"]).max() <= 1e-7
 
 
 def test_config_dims():

@@ -11,7 +11,7 @@ from rpo_amd.config import flops_image, flops_text, vit_b16, vit_l14
 
 from helpers import CASES, load_golden, oracle_for, workload
 
-FAST = ["d1_k4_b2", "d2_k8_b3", "d2_k24_b2_init", "d2_k48_b2"]
+FAST = ["d1_k4_b2", "d2_k8_b3", "d2_k24_b2_init", "d2_k16_b2", "d2_k48_b2"]
 
 
 def test_tokens_fixture_matches_survey():

@@ -13,7 +13,7 @@ from rpo_amd.config import vit_b16
 from helpers import load_golden, oracle_for
 
 
-@pytest.mark.parametrize("tag", ["d1_k4_b2", "d2_k8_b3", "d2_k48_b2"])
+@pytest.mark.parametrize("tag", ["d1_k4_b2", "d2_k8_b3", "d2_k16_b2", "d2_k48_b2"])
 def test_rows_step_matches_dense_and_reference(tag):
     g = load_golden(tag)
     m, image, label = oracle_for(tag)

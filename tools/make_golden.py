@@ -17,6 +17,13 @@ What is captured:
       (depth, K, B) including the full 12-layer ViT-B/16 at K=24, B=4
   G4  prompt rows after every block (depth 2) for kernel-level bisecting
   G5  prompts after 1 and 4 SGD steps with explicit (lr, momentum, wd)
+  G7  the reference's OWN prompt initialisation (trainers/rpo.py:63-67, :77-81 draw from the global
+      RNG) with torch.manual_seed set right before CustomCLIP is constructed, + the logits it gives:
+      pins the reference-shaped constructor of rpo_amd.custom_clip
+  G8  a checkpoint directory in the layout the reference's reader consumes
+      (trainers/rpo.py:325-357: <dir>/prompt_learner/model-best.pth.tar and model.pth.tar-<epoch>
+      with "state_dict" / "epoch", plus the token_prefix / token_suffix keys it deletes) holding
+      the reference's prompts after one SGD step, and the eval logits those prompts give
 """
 from __future__ import annotations
 
@@ -70,7 +77,7 @@ def _reference():
     return ref_clip, CLIP, ref_rpo
 
 
-def build_reference_model(CLIP, ref_rpo, cfg, sd_np, classnames):
+def build_reference_model(CLIP, ref_rpo, cfg, sd_np, classnames, seed=None):
     clip_model = CLIP(cfg.embed, cfg.image_size, cfg.layers_v, cfg.d_v, cfg.patch,
                       cfg.context, cfg.vocab, cfg.d_t, cfg.heads_t, cfg.layers_t).float()
     missing = clip_model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()},
@@ -78,6 +85,8 @@ def build_reference_model(CLIP, ref_rpo, cfg, sd_np, classnames):
     assert not missing.missing_keys and not missing.unexpected_keys
     ns = types.SimpleNamespace
     rcfg = ns(TRAINER=ns(RPO=ns(K=cfg.K)), INPUT=ns(SIZE=(cfg.image_size, cfg.image_size)))
+    if seed is not None:          # the generator state PromptLearner.initialization_token starts from (CLIP's own
+        torch.manual_seed(seed)   # constructor draws too, so the seed is set between the two)
     model = ref_rpo.CustomCLIP(rcfg, list(classnames), PROMPT_TEMPLATE, clip_model)
     for name, p in model.named_parameters():          # trainers/rpo.py:258-260
         if "prompt_learner" not in name:
@@ -147,6 +156,7 @@ def main() -> None:
         ("d1_k4_b2", 1, 4, 2, np.log(100.0), dict(rows=False, sgd=False)),
         ("d2_k8_b3", 2, 8, 3, np.log(100.0), dict(rows=True, sgd=True)),
         ("d2_k24_b2_init", 2, 24, 2, np.log(1 / 0.07), dict(rows=False, sgd=False)),
+        ("d2_k16_b2", 2, 16, 2, np.log(100.0), dict(rows=False, sgd=False)),
         ("d2_k48_b2", 2, 48, 2, np.log(100.0), dict(rows=False, sgd=False)),
         ("d12_k24_b4", 12, 24, 4, np.log(100.0), dict(rows=False, sgd=True)),
     ]
@@ -198,6 +208,49 @@ def main() -> None:
                              loss=float(loss), bytes=os.path.getsize(path))
         print(tag, "loss", float(loss), "|logits|max", float(logits.abs().max()),
               "|g_text|max", float(gt.abs().max()), "|g_img|max", float(gi.abs().max()))
+    # ---- G7: seeded reference initialisation ------------------------------------
+    cfg = vit_b16(layers_v=1, layers_t=1, K=4)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    model = build_reference_model(CLIP, ref_rpo, cfg, sd, OXFORD_PETS_BASE_CLASSES, seed=3)
+    image = torch.from_numpy(synth.images(cfg, 2))
+    model.prompt_learner.eval()
+    with torch.no_grad():
+        logits = model(image)
+    np.savez_compressed(os.path.join(out_dir, "ref_init_seed3_d1_k4.npz"),
+                        text_prompt=model.prompt_learner.text_prompt.detach().numpy(),
+                        img_prompt=model.prompt_learner.img_prompt.detach().numpy(), logits=logits.numpy(),
+                        seed=np.int64(3))
+    print("G7 init |text_prompt|max", float(model.prompt_learner.text_prompt.abs().max()))
+
+    # ---- G8: checkpoint in the reference reader's layout ------------------------
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    set_prompts(model, tp, ip)
+    pl = model.prompt_learner
+    pl.train()
+    opt = torch.optim.SGD(pl.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    model.text_x = model.text_x.detach()
+    l_ = model(image, torch.from_numpy(synth.labels(cfg, 2)))
+    opt.zero_grad(); l_.backward(); opt.step()
+    pl.eval()
+    model.text_x = model.text_x.detach()
+    with torch.no_grad():
+        logits = model(image)
+    ck_dir = os.path.join(out_dir, "ckpt_d1_k4", "prompt_learner")
+    os.makedirs(ck_dir, exist_ok=True)
+    state = {k: v.detach().clone() for k, v in pl.state_dict().items()}
+    # CoOp-era checkpoints carry these two; the reader deletes them (trainers/rpo.py:348-352)
+    state["token_prefix"] = torch.zeros(2, 1, cfg.d_t)
+    state["token_suffix"] = torch.zeros(2, 3, cfg.d_t)
+    # Dassl's save_checkpoint (un-vendored) stores these five keys; the reader uses the first two
+    ck = {"state_dict": state, "epoch": 2, "optimizer": opt.state_dict(), "scheduler": None, "val_result": 12.5}
+    torch.save(ck, os.path.join(ck_dir, "model.pth.tar-2"))
+    torch.save(ck, os.path.join(ck_dir, "model-best.pth.tar"))
+    np.savez_compressed(os.path.join(out_dir, "ref_ckpt_d1_k4.npz"),
+                        text_prompt=pl.text_prompt.detach().numpy(), img_prompt=pl.img_prompt.detach().numpy(),
+                        logits=logits.numpy(), momentum_text=opt.state_dict()["state"][0]["momentum_buffer"].numpy(),
+                        momentum_img=opt.state_dict()["state"][1]["momentum_buffer"].numpy())
+    print("G8 checkpoint written", ck_dir)
+
     with open(os.path.join(out_dir, "manifest.json"), "w") as f:
         json.dump(dict(generator="tools/make_golden.py", torch=torch.__version__,
                        numpy=np.__version__, cases=manifest), f, indent=1)
