@@ -230,8 +230,9 @@ int rpo_preprocess_batch(const uint8_t* src, int64_t src_bytes, const rpo_image_
 
 /* Empirical peaks of the box, used as second denominators by bench.py.
  * rpo_probe_peak_mfma: `blocks` workgroups of 4 waves each run `iters` rounds of 4 independent 32x32 MFMAs
- * (which: 0 = 32x32x16 bf16, 1 = 32x32x2 f32) on non-zero operands; *flops receives the flop count of the
- * launch (time it with events).  rpo_probe_peak_copy: 16-B-per-lane grid-stride copy of `bytes` bytes. */
+ * (which: 0 = 32x32x16 bf16 on non-zero operands, 1 = 32x32x2 f32, 2 = 32x32x16 bf16 on ZERO operands: the chip
+ * clocks to its power budget, so 0 and 2 bracket the sustained and the datasheet rate); *flops receives the flop
+ * count of the launch (time it with events).  rpo_probe_peak_copy: 16-B-per-lane grid-stride copy of `bytes` bytes. */
 int rpo_probe_peak_mfma(int which, int blocks, int iters, float* sink, double* flops, void* stream);
 int rpo_probe_peak_copy(const void* src, void* dst, int64_t bytes, void* stream);
 

@@ -231,11 +231,16 @@ __global__ __launch_bounds__(256) void peak_mfma_kernel(float* sink, int iters) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   // random-looking, non-zero operands: zero-filled operands run faster than real data on this chip
-  const float seed = 0.001f * (float)((threadIdx.x * 37 + blockIdx.x * 11) % 251) - 0.125f;
-  if constexpr (WHICH == 0) {
+  // WHICH == 2: the same bf16 loop on ZERO operands -- the chip clocks to its power budget, so zero operands run at
+  // ~2.4 GHz and random ones at ~1.65-1.9 GHz (guide: DVFS give-back); the two readings bracket what "peak" means here
+  const float seed = WHICH == 2 ? 0.0f : 0.001f * (float)((threadIdx.x * 37 + blockIdx.x * 11) % 251) - 0.125f;
+  if constexpr (WHICH == 0 || WHICH == 2) {
     bf16x8_t a, b;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + 0.01f * i); b[i] = (__bf16)(0.5f - seed * (i + 1)); }
+    for (int i = 0; i < 8; ++i) {
+      a[i] = (__bf16)(WHICH == 2 ? 0.0f : seed + 0.01f * i);
+      b[i] = (__bf16)(WHICH == 2 ? 0.0f : 0.5f - seed * (i + 1));
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
@@ -402,11 +407,12 @@ extern "C" int rpo_probe_mfma(int which, const float* a, const float* b, float* 
 }
 
 extern "C" int rpo_probe_peak_mfma(int which, int blocks, int iters, float* sink, double* flops, void* stream) {
-  if (!sink || !flops || blocks <= 0 || iters <= 0 || (which != 0 && which != 1)) return RPO_E_BADARG;
+  if (!sink || !flops || blocks <= 0 || iters <= 0 || which < 0 || which > 2) return RPO_E_BADARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (which == 0) hipLaunchKernelGGL(peak_mfma_kernel<0>, dim3(blocks), dim3(256), 0, s, sink, iters);
+  else if (which == 2) hipLaunchKernelGGL(peak_mfma_kernel<2>, dim3(blocks), dim3(256), 0, s, sink, iters);
   else hipLaunchKernelGGL(peak_mfma_kernel<1>, dim3(blocks), dim3(256), 0, s, sink, iters);
-  const double per_mfma = which == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;
+  const double per_mfma = which != 1 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 2;
   *flops = per_mfma * 4.0 * (double)iters * 4.0 * (double)blocks;   // 4 accumulators, 4 waves per block
   return rpo_launch_status();
 }

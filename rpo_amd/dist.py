@@ -54,6 +54,14 @@ class GradSync:
     def grad_scale(self) -> float:
         return 1.0 / self.world_size
 
+    def describe(self) -> str:
+        """What carries the per-step collective (for the bench line)."""
+        if not self.enabled:
+            return "none (single rank)"
+        self._pg()
+        b = dist.get_backend()
+        return f"{'rccl' if b == 'nccl' else b} all-reduce of the flat prompt-gradient buffer, {dist.get_world_size()} ranks"
+
     def shard(self, global_batch: int) -> Tuple[int, int]:
         """(first image, count) of this rank's contiguous shard; shards must be equal so that
         the mean of shard means is the global mean."""

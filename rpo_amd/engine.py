@@ -29,7 +29,10 @@ from . import ops
 from ._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH, EPI_QGELU_BWD
 from .config import RPOConfig
 
+import contextlib
+
 SCALE = 1.0 / math.sqrt(64.0)
+_NO_PROBE = contextlib.nullcontext()
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
 # d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.  Tuned at step level:
 # 4, 6, 8 slabs for c_fc and 3, 4 for the q-projection were slower (more slabs cost output bandwidth).
@@ -76,6 +79,7 @@ class Engine:
             self._pack(state_dict, tokens)
             self._alloc()
         self.text_cache_ready = False
+        self.probe = None               # optional callable(name) -> context manager bracketing one launch (bench.py)
         self.text_f_version = -1        # prompts version the cached eval text features belong to
         self.params_version = 0         # bumped by whoever changes the prompts (optimiser step, load)
 
@@ -220,6 +224,9 @@ class Engine:
             ops.gemm_nt(g, blk.w_proj, x, EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
         self.text_cache_ready = True
 
+    def _timed(self, name: str):
+        return _NO_PROBE if self.probe is None else self.probe(name)
+
     # ------------------------------------------------------------------ forward pieces
     def _text_forward(self, train: bool) -> None:
         cfg = self.cfg
@@ -257,8 +264,10 @@ class Engine:
             ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
             if l < last:
                 # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
-                ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
-                ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
+                with self._timed("in_proj"):
+                    ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
+                with self._timed("attn_fwd"):
+                    ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
                 lo = 0
             else:
                 # Last block: only its K prompt rows are consumed (ln_post reads x[:, -K:], rpo.py:210; the CLS feature
@@ -269,11 +278,16 @@ class Engine:
                 ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE,
                                       q_first=N)
                 lo = Rf
-            ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:])
-            ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
-            ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
-                        aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
-            ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:])
+            timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
+            with timed("out_proj"):
+                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:])
+            with timed("ln_2"):
+                ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
+            with timed("c_fc"):
+                ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
+                            aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
+            with timed("c_proj"):
+                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:])
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

@@ -197,7 +197,7 @@ def probe_mfma(which: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return d
 
 
-def probe_peaks(device: torch.device, which: int = 0) -> dict:
+def probe_peaks(device: torch.device, which: int = 0, copy: bool = True) -> dict:
     """Empirical peaks of this GPU: sustained MFMA TFLOP/s of a pure-MFMA loop (8 waves per SIMD-pair resident,
     non-zero operands) and GB/s of a 1 GiB stream copy (read + write bytes).  ~0.2 s."""
     import ctypes
@@ -205,7 +205,7 @@ def probe_peaks(device: torch.device, which: int = 0) -> dict:
     sink = torch.zeros(4, dtype=torch.float32, device=device)
     flops = ctypes.c_double(0.0)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    blocks, iters = 256 * 8, 4096 if which == 0 else 2048
+    blocks, iters = 256 * 8, 4096 if which != 1 else 2048
     for timed in (False, True):
         if timed:
             ev[0].record()
@@ -213,6 +213,9 @@ def probe_peaks(device: torch.device, which: int = 0) -> dict:
               "rpo_probe_peak_mfma")
         if timed:
             ev[1].record()
+    if not copy:
+        torch.cuda.synchronize(device)
+        return {"mfma_tflops": flops.value / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12}
     n = 1 << 29
     src = torch.empty(n, dtype=torch.uint8, device=device).fill_(1)
     dst = torch.empty_like(src)

@@ -239,26 +239,23 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
-    assert np.isfinite(d["config"]["final_loss"])
+    assert np.isfinite(d["config"]["final_loss"]) and d["config"]["collective"].startswith("rccl")
 
 
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
-    """The N = 2 control flow of bench.py end to end on this one-GPU box: both ranks on cuda:0, gloo instead of RCCL
-    (RCCL refuses two ranks on one device).  Sharded synthetic batches, prompt broadcast, per-step gradient
-    all-reduce, barriers, max-over-ranks timing, rank 0 prints the one JSON line with the GLOBAL batch."""
+    """The N = 2 control flow of bench.py end to end on this one-GPU box, launched the way the driver launches N = 1:
+    plain `python bench.py --gpus 2 ...` (no launcher, no WORLD_SIZE) -- the script re-executes itself under
+    torch.distributed.run.  Both ranks on cuda:0, gloo instead of RCCL (RCCL refuses two ranks on one device).
+    Sharded synthetic batches, prompt broadcast, per-step gradient all-reduce, barriers, max-over-ranks timing, rank 0
+    prints the one JSON line with the GLOBAL batch."""
     import json
-    import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, RPO_DIST_BACKEND="gloo", RPO_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RPO_DIST_BACKEND="gloo", RPO_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -266,7 +263,9 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert d["scaling"] == "weak" and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+    assert "2 ranks" in d["config"]["collective"]
     assert "cpu_baseline" not in d and "precision" not in d      # N = 1 only
+    assert d["roofline"]["dominant_kernel"]["avg_us"] > 0
 
 
 @pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1), (4, 300, 2)])
