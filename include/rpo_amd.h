@@ -84,7 +84,7 @@ typedef struct rpo_gemm_args {
                                     slice s writes its partial product to C + s * split_stride; the
                                     consumer (rpo_layernorm_bwd's dy_splits) adds the slabs in order    */
   int64_t split_stride;          /* elements between slabs (>= M * ldc)                            */
-  int32_t tile_config;           /* 0 = choose by shape; for benchmarking: 2 = 128x128 tiles, 3 = 256x256 (bf16
+  int32_t tile_config;           /* 0 = choose by shape; for benchmarking: 2 = 128x128 tiles, 8 = 256x256 one wave per SIMD, 3 = 256x256 (bf16
                                     in/out, BIAS / BIAS_QGELU only, else falls through), 5 = 64x64, 6 = 64x128,
                                     7 = 256x256 ping-pong schedule (same conditions as 3; what 0 picks there) */
 } rpo_gemm_args;

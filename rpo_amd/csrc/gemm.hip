@@ -218,22 +218,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   __builtin_amdgcn_s_barrier();              // everybody is done reading the last stage
   if constexpr (PRECONV) {
     const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
-    float4 bias_r[CF::WN_T][4];
 #pragma unroll
-    for (int tn = 0; tn < CF::WN_T; ++tn)
+    for (int tn = 0; tn < CF::WN_T; ++tn) {      // tn outermost: 4 bias quads live at a time (the one-wave-per-SIMD
+      float4 bias_r[4];                          // kernel arrives here with 256 accumulators)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        bias_r[tn][g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        bias_r[g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int tm = 0; tm < CF::WM_T; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < CF::WN_T; ++tn)
+      for (int tm = 0; tm < CF::WM_T; ++tm)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
           const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
-          const float4 b4 = bias_r[tn][g];
+          const float4 b4 = bias_r[g];
           float4 v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
                                  acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
           if (EPI == RPO_EPI_BIAS_QGELU) {
@@ -245,6 +243,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
               make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         }
+    }
     __syncthreads();
     constexpr int CPR = BN / 8;                       // 16-B chunks per row
     constexpr int RPP = CF::THREADS / CPR;            // rows per pass
@@ -686,6 +685,8 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
   RPO_STAMP(61);
 }
 
+#include "gemm_w4.inc"
+
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
   static unsigned long long lds_ok = 0;
@@ -723,9 +724,14 @@ int launch(const GemmParams& p, hipStream_t s) {
 #endif
     const bool fills = tiles * 100 >= rounds * 256 * RPO_FILL_PCT;
     const bool ok = p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C);
-    // the ping-pong kernel is bit-identical to CfgBig and 3-8 % faster; CfgBig stays selectable (tile_config 3)
-    if (ok && (p.force_cfg == 7 || (p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills)))
-      return launch_pp<TOut, EPI>(p, s);
+    // one-wave-per-SIMD kernel (gemm_w4.inc): 32-bit byte offsets inside the operand matrices, at least two 64-deep
+    // k-tiles.  Bit-identical to the ping-pong kernel (tile_config 7) and the lock-step 256x256 one (3) and faster
+    // than both (in-proj at B=32: 28.1 vs 34.3 / 29.5 us on one box), so it is what the heuristic picks.
+    const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+    const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK;
+    const bool wants_big = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills;
+    if (w4_ok && (p.force_cfg == 8 || wants_big)) return launch_w4<TOut, EPI>(p, s);
+    if (ok && (p.force_cfg == 7 || wants_big)) return launch_pp<TOut, EPI>(p, s);
     if (ok && p.force_cfg == 3) return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
   }
   // small-M GEMMs (prompt rows: backward, text tower) are a latency chain on few CUs: 64x64 tiles give 4x

@@ -173,6 +173,41 @@ def test_gemm_pingpong_256_bit_identical_and_race_screen(M, N, K):
                 assert torch.equal(out, outs[7][0]), "ping-pong kernel is not deterministic: LDS race"
 
 
+@pytest.mark.parametrize("M,N,K", [(7072, 2304, 768), (7072, 3072, 768), (4096, 4096, 128), (2048, 1536, 256),
+                                   (7000, 2304, 192), (6500, 2560, 3072), (3000, 2312, 192), (257, 264, 128)])
+def test_gemm_one_wave_per_simd_256_bit_identical_and_race_screen(M, N, K):
+    """The one-wave-per-SIMD 256x256 kernel (tile_config 8, hand-scheduled asm k-loop): against float64,
+    bit-identical to the lock-step 128x128 kernel (same k-order per output), M / N tails, K from 128 (four 32-deep
+    tiles: one steady-state iteration + the three-tile tail) upwards, and a race screen -- 25 back-to-back launches
+    must all give the same bits."""
+    from rpo_amd import _lib as L
+    o = ops()
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias = rnd((N,), 3)
+    acc = q(a, "bf16") @ q(w, "bf16").t()
+    ad, wd, bd = a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), bias.to(dev())
+    row0 = max(M - 300, 0)
+    ref_cfg = 2
+    for epi, ref in ((L.EPI_BIAS, acc + bias.double()), (L.EPI_BIAS_QGELU, R.qgelu(acc + bias.double()))):
+        outs = {}
+        for cfg in (8, ref_cfg):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+            kw = dict(bias=bd)
+            if epi == L.EPI_BIAS_QGELU:
+                kw.update(aux_row0=row0, aux=torch.full((M - row0, N), float("nan"), device=dev()))
+            o.gemm_nt(ad, wd, out, epi, tile_config=cfg, **kw)
+            outs[cfg] = (out, kw.get("aux"))
+        close(outs[8][0], ref, "bf16", f"w4 gemm epi {epi}")
+        assert torch.equal(outs[8][0], outs[ref_cfg][0]), f"tile_config {ref_cfg} differs from the one-wave-per-SIMD kernel"
+        if epi == L.EPI_BIAS_QGELU:
+            assert torch.equal(outs[8][1], outs[ref_cfg][1])
+        if epi == L.EPI_BIAS:
+            for _ in range(25):
+                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+                o.gemm_nt(ad, wd, out, epi, tile_config=8, bias=bd)
+                assert torch.equal(out, outs[8][0]), "one-wave-per-SIMD kernel is not deterministic: LDS race"
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_gemm_split_k_feeds_layernorm_bwd(mode):
     """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""

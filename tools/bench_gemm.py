@@ -44,7 +44,7 @@ for name, M, N, K, epi, odt, split in SHAPES:
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
     res = []
-    cfgs = [int(c) for c in os.environ.get('BENCH_CFGS', '').split(',') if c] if ONLY is not None else [2, 5, 6]
+    cfgs = [int(c) for c in os.environ.get('BENCH_CFGS', '').split(',') if c] if (ONLY is not None or 'BENCH_CFGS' in os.environ) else [2, 5, 6]
     for cfg in [0] + cfgs:
         for _ in range(3):
             ops.gemm_nt(a, w, out, epi, tile_config=cfg, **kw)
