@@ -43,7 +43,7 @@ from rpo_amd import synth  # noqa: E402
 from rpo_amd.config import flops_image, flops_last_block_dead, flops_step, flops_text, vit_b16, vit_l14  # noqa: E402
 from rpo_amd.dist import GradSync  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}       # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def usable_cores() -> int:
@@ -165,7 +165,7 @@ def time_step_kernels(trainer, image, label, steps: int = 4):
     Rf = B * cfg.n_frozen
     flops = {"in_proj": 2.0 * (R * 3 * d - (R - Rf) * 2 * d) * d, "out_proj": 2.0 * R * d * d, "c_fc": 2.0 * R * 4 * d * d,
              "c_proj": 2.0 * R * 4 * d * d, "attn_fwd": 4.0 * B * cfg.heads_v * cfg.seq_v * cfg.n_frozen * 64}
-    peak = PEAK_TFLOPS["bf16" if eng.act != torch.float32 else "f32"]
+    peak = PEAK_TFLOPS["f32" if eng.act == torch.float32 else "bf16"]
     out = {}
     for k, v in sorted(us.items()):
         t = max(v - empty, 1e-3)
@@ -178,25 +178,29 @@ def time_step_kernels(trainer, image, label, steps: int = 4):
 
 
 def precision_report(cfg, sd, toks, prompts, dev, batch: int):
-    """bf16 throughput mode vs the f32 parity mode of the SAME kernels on one identical batch: the bf16 error is
+    """The two 16-bit throughput modes vs the f32 parity mode of the SAME kernels on one identical batch: the error is
     reported, not assumed (the f32 mode itself is pinned to the reference goldens at <= 1e-3 by tests/)."""
     from rpo_amd.custom_clip import CustomCLIP
     img = torch.from_numpy(synth.images(cfg, batch, seed=31)).to(dev)
     lab = torch.from_numpy(synth.labels(cfg, batch, seed=32)).to(dev)
     res = {}
-    for name, act in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, act in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         m = CustomCLIP(cfg, sd, toks, dev, act, max_batch=batch, prompts=prompts)
         m.engine.forward_backward(img, lab)
         torch.cuda.synchronize()
         res[name] = (m.engine.logits[:batch].clone(), m.engine.loss.clone(), m.engine.g_text.clone(), m.engine.g_img.clone())
         del m
-    (lf, sf, tf, gf), (lb, sb, tb, gb) = res["f32"], res["bf16"]
+    lf, sf, tf, gf = res["f32"]
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    return {"reference": "f32 mode of the same kernels (pinned to the reference within 1e-3 by tests/)", "batch": batch,
-            "logits_max_abs_err": round(float((lb - lf).abs().max()), 4), "logits_max_abs": round(float(lf.abs().max()), 3),
-            "loss_abs_err": round(abs(float(sb) - float(sf)), 5),
-            "g_text_rel_err": round(rel(tb, tf), 4), "g_img_rel_err": round(rel(gb, gf), 4),
-            "argmax_agreement": round(float((lb.argmax(-1) == lf.argmax(-1)).float().mean()), 3)}
+    out = {"reference": "f32 mode of the same kernels (pinned to the reference within 1e-3 by tests/)", "batch": batch,
+           "logits_max_abs": round(float(lf.abs().max()), 3)}
+    for name in ("bf16", "f16"):
+        lb, sb, tb, gb = res[name]
+        out[name] = {"logits_max_abs_err": round(float((lb - lf).abs().max()), 4),
+                     "loss_abs_err": round(abs(float(sb) - float(sf)), 5),
+                     "g_text_rel_err": round(rel(tb, tf), 4), "g_img_rel_err": round(rel(gb, gf), 4),
+                     "argmax_agreement": round(float((lb.argmax(-1) == lf.argmax(-1)).float().mean()), 3)}
+    return out
 
 
 def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
@@ -324,7 +328,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--K", type=int, default=24)
     ap.add_argument("--model", default="ViT-B/16", choices=["ViT-B/16", "ViT-L/14"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision", action="store_true", help="skip the bf16-vs-f32 error report")
@@ -347,7 +351,7 @@ def main() -> None:
     lens = synth.len_prompts(toks)
     sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
     prompts = synth.prompts(cfg, sd, seed=7)
-    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    act = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     tr = RPO(cfg, sd, toks, OptimConfig(), dev, act, batch_size=args.batch, num_batches=10 ** 9,
              use_graph=not args.no_graph, sync=sync, prompts=prompts)
 
@@ -424,7 +428,7 @@ def main() -> None:
             out["input_pipeline"] = time_input_pipeline(dev, args.batch)
         if args.eval_batch > 0:
             out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)
-        if args.dtype == "bf16" and sync.world_size == 1 and not args.no_precision:
+        if args.dtype != "f32" and sync.world_size == 1 and not args.no_precision:
             del tr
             torch.cuda.empty_cache()
             out["precision"] = precision_report(cfg, sd, toks, prompts, dev, min(args.batch, 8))

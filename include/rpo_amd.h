@@ -17,7 +17,7 @@
  *     void*; 0 = the null stream) and returns immediately
  *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = RPO_E_* argument
  *     error (nothing was enqueued); rpo_error_string() decodes any of them
- *   - dtype arguments take RPO_F32 / RPO_BF16.  "act dtype" is the storage type of
+ *   - dtype arguments take RPO_F32 / RPO_BF16 / RPO_F16.  "act dtype" is the storage type of
  *     activations and frozen weights: RPO_F32 = parity mode (exact-f32 MFMA,
  *     v_mfma_f32_32x32x2_f32), RPO_BF16 = throughput mode (bf16 storage,
  *     v_mfma_f32_32x32x16_bf16, fp32 accumulate).  The residual stream, LayerNorm
@@ -43,7 +43,7 @@ extern "C" {
 
 #define RPO_ABI_VERSION 1
 
-enum { RPO_F32 = 0, RPO_BF16 = 1 };
+enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
 enum {
   RPO_E_BADARG = -1,   /* null pointer / non-positive size */

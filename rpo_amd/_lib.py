@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librpo_hip.so")
 
-RPO_F32, RPO_BF16 = 0, 1
+RPO_F32, RPO_BF16, RPO_F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH = range(6)
 
 c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p

@@ -137,13 +137,17 @@ def act_dtype_for_prec(prec: str):
     """`TRAINER.RPO.PREC` (configs/trainers/RPO/main_K24.yaml:35, trainers/rpo.py:247-249,278,298-304) -> the
     activation / weight storage dtype of the HIP engine.
 
-    "fp32": exact-f32 MFMA path (the parity mode).  "fp16" (the reference's GPU default: fp16 weights and prompts,
-    plain SGD, no loss scaling) and "amp" (fp32 master weights, autocast forward, GradScaler) both map to the bf16
-    storage mode: bf16 weights / activations, fp32 accumulation, fp32 residual stream, fp32 prompts and optimiser
-    state.  That is the same "16-bit tensors, 32-bit accumulate" contract with fp32 range, so no loss scaling is
-    needed and there is no GradScaler counterpart; a native fp16 storage mode is not implemented."""
+    "fp32": exact-f32 MFMA path (the parity mode).  "fp16" (the reference's GPU default: fp16 weights and
+    activations, plain SGD, no loss scaling) -> native IEEE half storage: f16 weights / activations on
+    v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Unlike the reference's fp16 mode the residual stream, LayerNorm,
+    softmax, logits, the prompts and the optimiser state stay fp32, so nothing here can underflow in the backward
+    and there is no loss scaling to reproduce.  "amp" (fp32 master weights + autocast + GradScaler) maps onto the
+    same storage mode: autocast's fp16 GEMMs with fp32 accumulate are what the f16 mode computes, its fp32 master
+    copy of the only trainable state is what the engine keeps anyway, and GradScaler's scale / unscale is the
+    identity on a gradient that is never stored in fp16.  bf16 remains available as `torch.bfloat16` (same MFMA
+    rate, fp32 exponent range, 8 x the rounding error)."""
     import torch
-    table = {"fp32": torch.float32, "fp16": torch.bfloat16, "amp": torch.bfloat16}
+    table = {"fp32": torch.float32, "fp16": torch.float16, "amp": torch.float16}
     if prec not in table:
         raise ValueError(f"TRAINER.RPO.PREC must be one of {sorted(table)} (trainers/rpo.py:247), got {prec!r}")
     return table[prec]

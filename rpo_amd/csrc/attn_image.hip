@@ -32,8 +32,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <typename T, int NT> struct AL;  // LDS layout
-template <int NT> struct AL<bf16_t, NT> {
+template <typename T, int NT> struct AL {   // LDS layout, 16-bit storage (bf16 / f16)
   static constexpr int NPAD = NT * 32;
   static constexpr int KROW = 144;                 // bytes per K (or row-major V) row: 128 + 16 pad
   static constexpr int K_BYTES = NPAD * KROW;
@@ -53,11 +52,11 @@ template <int NT> struct AL<float, NT> {
   static constexpr int BWD_BYTES = BWD_STAGE > PART_BYTES ? BWD_STAGE : PART_BYTES;
 };
 
-__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+template <typename T> __device__ __forceinline__ bf16x8_t pack8(const float* p) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 u;
-  u[0] = pack_bf16x2(p[0], p[1]); u[1] = pack_bf16x2(p[2], p[3]);
-  u[2] = pack_bf16x2(p[4], p[5]); u[3] = pack_bf16x2(p[6], p[7]);
+  u[0] = pack2<T>(p[0], p[1]); u[1] = pack2<T>(p[2], p[3]);
+  u[2] = pack2<T>(p[4], p[5]); u[3] = pack2<T>(p[6], p[7]);
   return __builtin_bit_cast(bf16x8_t, u);
 }
 __device__ __forceinline__ bf16x8_t join8(uint2 lo, uint2 hi) {
@@ -69,30 +68,31 @@ __device__ __forceinline__ bf16x8_t join8(uint2 lo, uint2 hi) {
 
 // B-operand identity fragment for the k-step pair (ks2 = 0, 1) of a 32-wide d' tile: element jj of lane
 // (j = l31, half) is I[k][j] with k = 16*ks2 + 8*half + jj
-__device__ __forceinline__ bf16x8_t ident_frag(int ks2, int l31, int half) {
+template <typename T> __device__ __forceinline__ bf16x8_t ident_frag(int ks2, int l31, int half) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 u;
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     const int k0 = 16 * ks2 + 8 * half + 2 * w;
-    u[w] = (k0 == l31 ? 0x3F80u : 0u) | (k0 + 1 == l31 ? 0x3F800000u : 0u);
+    u[w] = (k0 == l31 ? One16<T>::lo : 0u) | (k0 + 1 == l31 ? One16<T>::hi : 0u);
   }
   return __builtin_bit_cast(bf16x8_t, u);
 }
 // rows[4] = the four 16-element A fragments (d = 0..63) of 32 rows of a row-major matrix M; returns the
 // A fragments of M^T for d' tile dt: out[g2] covers this kernel's key slots 8*g2 .. 8*g2+7
+template <typename T>
 __device__ __forceinline__ void transpose_tile(const bf16x8_t (&rows)[4], int dt, const bf16x8_t& i0,
                                                const bf16x8_t& i1, bf16x8_t (&out)[2]) {
   f32x16_t d;
 #pragma unroll
   for (int r = 0; r < 16; ++r) d[r] = 0.f;
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rows[2 * dt], i0, d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rows[2 * dt + 1], i1, d, 0, 0, 0);
+  d = mfma16<T>(rows[2 * dt], i0, d);
+  d = mfma16<T>(rows[2 * dt + 1], i1, d);
   float f[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) f[r] = d[r];
-  out[0] = pack8(f);
-  out[1] = pack8(f + 8);
+  out[0] = pack8<T>(f);
+  out[1] = pack8<T>(f + 8);
 }
 
 // ---- staging ---------------------------------------------------------------------------
@@ -175,10 +175,9 @@ __device__ __forceinline__ void stage_rows_f32(float* dst, const float* src, int
 }
 
 // ---- per-lane operand fragments of one 32-row tile loaded straight from global ----------
-template <typename T> struct RowFrag;
-template <> struct RowFrag<bf16_t> {
+template <typename T> struct RowFrag {        // 16-bit storage
   bf16x8_t f[4];
-  __device__ __forceinline__ void load(const bf16_t* rowp, int half) {
+  __device__ __forceinline__ void load(const T* rowp, int half) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 16 + half * 8);
   }
@@ -205,7 +204,7 @@ __device__ __forceinline__ f32x16_t tile_times_frag(const char* lds, int t, cons
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + ks * 32);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.f[ks], acc, 0, 0, 0);
+      acc = mfma16<T>(a, fr.f[ks], acc);
     }
   } else {
     const float* rowp = reinterpret_cast<const float*>(lds) + (32 * t + l31) * 65 + half * 32;
@@ -263,11 +262,11 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
     const int lane = l31 + 32 * half;
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-      const bf16x8_t b = pack8(wf + 8 * g2);
+      const bf16x8_t b = pack8<T>(wf + 8 * g2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(m_lds + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, o[dt], 0, 0, 0);
+        o[dt] = mfma16<T>(a, b, o[dt]);
       }
     }
   } else {
@@ -322,10 +321,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
         vrows[ti][kk] = __builtin_bit_cast(bf16x8_t, z);
       }
     }
-    stage_rows_bf16<NT, 512>(ks, kb, ld, N, tid);
+    stage_rows_bf16<NT, 512>(ks, reinterpret_cast<const bf16_t*>(kb), ld, N, tid);
     RPO_STAMP(1);
     // V^T fragments: wave w transposes key tiles w, w+8 on the matrix core
-    const bf16x8_t i0 = ident_frag(0, l31, half), i1 = ident_frag(1, l31, half);
+    const bf16x8_t i0 = ident_frag<T>(0, l31, half), i1 = ident_frag<T>(1, l31, half);
 #pragma unroll
     for (int ti = 0; ti < (NT + 7) / 8; ++ti) {
       const int t = wave + 8 * ti;
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           bf16x8_t fr[2];
-          transpose_tile(vrows[ti], dt, i0, i1, fr);
+          transpose_tile<T>(vrows[ti], dt, i0, i1, fr);
 #pragma unroll
           for (int g2 = 0; g2 < 2; ++g2)
             *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
   float4* part_w = part_u + 4 * 8 * 64;
   float* part_d = reinterpret_cast<float*>(part_w + 4 * 8 * 64);    // [4 waves][64 lanes]
   bf16x8_t i0, i1;
-  if constexpr (sizeof(T) == 2) { i0 = ident_frag(0, l31, half); i1 = ident_frag(1, l31, half); }
+  if constexpr (sizeof(T) == 2) { i0 = ident_frag<T>(0, l31, half); i1 = ident_frag<T>(1, l31, half); }
 
   const int nqt = (Kp + 31) / 32;
   for (int qt = 0; qt < nqt; ++qt) {
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
     qf.load(qr + prow * ldq + h * 64, half);
     df.load(da + prow * ldda + h * 64, half);
     if constexpr (sizeof(T) == 2) {
-      stage2_bf16<NT, 256>(ks, vs, kb, vb, ldkv, N, tid);          // K and V loads in ONE round trip
+      stage2_bf16<NT, 256>(ks, vs, reinterpret_cast<const bf16_t*>(kb), reinterpret_cast<const bf16_t*>(vb), ldkv, N, tid);          // K and V loads in ONE round trip
     } else {
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
@@ -482,11 +481,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           bf16x8_t ktf[2];
-          transpose_tile(krows, dt, i0, i1, ktf);  // K^T fragments of this key tile, in registers
+          transpose_tile<T>(krows, dt, i0, i1, ktf);  // K^T fragments of this key tile, in registers
 #pragma unroll
           for (int g2 = 0; g2 < 2; ++g2) {
-            u[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[g2], pack8(pw + 8 * g2), u[dt], 0, 0, 0);
-            w[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[g2], pack8(pp + 8 * g2), w[dt], 0, 0, 0);
+            u[dt] = mfma16<T>(ktf[g2], pack8<T>(pw + 8 * g2), u[dt]);
+            w[dt] = mfma16<T>(ktf[g2], pack8<T>(pp + 8 * g2), w[dt]);
           }
         }
       } else {
@@ -578,14 +577,18 @@ extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const vo
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Kp < 0 || q_first < 0 || q_first >= N + Kp)
     return RPO_E_BADARG;
   if (N > 288) return RPO_E_SHAPE;
-  if (dtype != RPO_F32 && dtype != RPO_BF16) return RPO_E_DTYPE;
-  const int esz = dtype == RPO_BF16 ? 2 : 4;
+  if (dtype != RPO_F32 && dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
+  const int esz = dtype == RPO_F32 ? 4 : 2;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !ok_ld(ld, esz) ||
       reinterpret_cast<uintptr_t>(out) % (4 * esz) || (ldo * esz) % (4 * esz)) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == RPO_BF16) {
     if (N <= 224) return launch_fwd<bf16_t, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
     return launch_fwd<bf16_t, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+  }
+  if (dtype == RPO_F16) {
+    if (N <= 224) return launch_fwd<f16_t, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+    return launch_fwd<f16_t, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
   }
   if (N <= 224) return launch_fwd<float, 7>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
   return launch_fwd<float, 9>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
@@ -596,8 +599,8 @@ extern "C" int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void
                                      int dtype, int B, int H, int N, int Kp, float scale, void* stream) {
   if (!q_rows || !k || !v || !da || !dq || B <= 0 || H <= 0 || N <= 0 || Kp <= 0) return RPO_E_BADARG;
   if (N > 288 || Kp > 128) return RPO_E_SHAPE;
-  if (dtype != RPO_F32 && dtype != RPO_BF16) return RPO_E_DTYPE;
-  const int esz = dtype == RPO_BF16 ? 2 : 4;
+  if (dtype != RPO_F32 && dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
+  const int esz = dtype == RPO_F32 ? 4 : 2;
   if (!aligned16(q_rows) || !aligned16(k) || !aligned16(v) || !aligned16(da) || !ok_ld(ldq, esz) ||
       !ok_ld(ldkv, esz) || !ok_ld(ldda, esz) || reinterpret_cast<uintptr_t>(dq) % (4 * esz) ||
       (lddq * esz) % (4 * esz)) return RPO_E_ALIGN;
@@ -605,6 +608,10 @@ extern "C" int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void
   if (dtype == RPO_BF16) {
     if (N <= 224) return launch_bwd<bf16_t, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
     return launch_bwd<bf16_t, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+  }
+  if (dtype == RPO_F16) {
+    if (N <= 224) return launch_bwd<f16_t, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+    return launch_bwd<f16_t, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
   }
   if (N <= 224) return launch_bwd<float, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
   return launch_bwd<float, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void text_attn_kernel(const T* __restrict__ q,
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          kd[2 * e] = __uint_as_float(kw[e] << 16); kd[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
-          vd[2 * e] = __uint_as_float(vw[e] << 16); vd[2 * e + 1] = __uint_as_float(vw[e] & 0xffff0000u);
+          kd[2 * e] = unpack1<T>((uint16_t)(kw[e] & 0xffffu)); kd[2 * e + 1] = unpack1<T>((uint16_t)(kw[e] >> 16));
+          vd[2 * e] = unpack1<T>((uint16_t)(vw[e] & 0xffffu)); vd[2 * e + 1] = unpack1<T>((uint16_t)(vw[e] >> 16));
         }
       } else {
 #pragma unroll
@@ -138,10 +138,12 @@ extern "C" int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, con
   if (!q || !kc || !vc || !out || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
   if (Lmax > 128) return RPO_E_SHAPE;
   {
-    const int esz = dtype == RPO_BF16 ? 2 : 4;
+    const int esz = dtype == RPO_F32 ? 4 : 2;
     if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_F16)
+    return launch<f16_t, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
   if (dtype == RPO_BF16)
     return launch<bf16_t, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
   if (dtype == RPO_F32)
@@ -156,10 +158,12 @@ extern "C" int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, con
   if (!q || !kc || !vc || !da || !dq || !len || n_cls <= 0 || rows <= 0 || Lmax <= 0 || H <= 0) return RPO_E_BADARG;
   if (Lmax > 128) return RPO_E_SHAPE;
   {
-    const int esz = dtype == RPO_BF16 ? 2 : 4;
+    const int esz = dtype == RPO_F32 ? 4 : 2;
     if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_F16)
+    return launch<f16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);
   if (dtype == RPO_BF16)
     return launch<bf16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);
   if (dtype == RPO_F32)

@@ -6,7 +6,12 @@
 #include "../../include/rpo_amd.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// raw IEEE binary16 bits (TRAINER.RPO.PREC = fp16 / amp, trainers/rpo.py:247-249): a distinct type, so that templates
+// can tell the two 16-bit storage formats apart
+struct f16_t { uint16_t v; };
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // also the 128-bit container of 8 halves of either format
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -27,6 +32,28 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
+// ---- the two 16-bit storage formats behind one set of helpers (T = bf16_t or f16_t) ------------------------------
+// Fragment registers are typed bf16x8_t for both (a 128-bit container); only conversion and the MFMA opcode differ.
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);          // f32 x2 -> 16-bit x2, RNE
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));                    // v_cvt_f16_f32, RNE
+}
+template <typename T> __device__ __forceinline__ float unpack1(uint16_t bits);
+template <> __device__ __forceinline__ float unpack1<bf16_t>(uint16_t bits) { return bf16_to_f32(bits); }
+template <> __device__ __forceinline__ float unpack1<f16_t>(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+template <typename T> struct One16;                                                          // bit pattern of 1.0
+template <> struct One16<bf16_t> { static constexpr uint32_t lo = 0x3F80u, hi = 0x3F800000u; };
+template <> struct One16<f16_t> { static constexpr uint32_t lo = 0x3C00u, hi = 0x3C000000u; };
+template <typename T> __device__ __forceinline__ f32x16_t mfma16(bf16x8_t a, bf16x8_t b, f32x16_t c);
+template <> __device__ __forceinline__ f32x16_t mfma16<bf16_t>(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_t mfma16<f16_t>(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
 template <typename T> struct ActIO;
 template <> struct ActIO<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -40,6 +67,14 @@ template <> struct ActIO<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
   static __device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  }
+};
+
+template <> struct ActIO<f16_t> {
+  static __device__ __forceinline__ float ld(const f16_t* p) { return unpack1<f16_t>(p->v); }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { p->v = (uint16_t)(pack2<f16_t>(v, 0.0f) & 0xffffu); }
+  static __device__ __forceinline__ void st4(f16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2<f16_t>(a, b), pack2<f16_t>(c, d));
   }
 };
 

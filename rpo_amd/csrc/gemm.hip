@@ -51,17 +51,14 @@ struct GemmParams {
 
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
 
-template <typename T> struct Tr;
-template <> struct Tr<bf16_t> {
+template <typename T> struct Tr {              // 16-bit storage: bf16_t or f16_t
   static constexpr int BK = 64, KSTEPS = 4;
   using frag_t = bf16x8_t;
   // rowp = start of the LDS row, sw = (row >> 1) & 7
   static __device__ __forceinline__ frag_t ldfrag(const char* rowp, int sw, int ks, int half) {
     return *reinterpret_cast<const frag_t*>(rowp + (((ks * 2 + half) ^ sw) << 4));
   }
-  static __device__ __forceinline__ f32x16_t mfma(frag_t a, frag_t b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ f32x16_t mfma(frag_t a, frag_t b, f32x16_t c) { return mfma16<T>(a, b, c); }
 };
 template <> struct Tr<float> {
   static constexpr int BK = 32, KSTEPS = 16;
@@ -240,8 +237,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
               *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
             v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
           }
-          *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
-              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+          if constexpr (sizeof(TOut) == 2)
+            *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
+                make_uint2(pack2<TOut>(v.x, v.y), pack2<TOut>(v.z, v.w));
         }
     }
     __syncthreads();
@@ -535,7 +533,7 @@ template <int N> __device__ __forceinline__ void pp_vmwait(int later) {   // `la
 }
 
 
-template <typename TOut, int EPI>
+template <typename TOut, int EPI>      // TOut = the 16-bit storage type of all three matrices
 __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CF = CfgPP;
@@ -607,7 +605,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
       for (int tn = 0; tn < CF::WN_T; ++tn)
 #pragma unroll
         for (int tm = 0; tm < CF::WM_T; ++tm)
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+          acc[tn][tm] = mfma16<TOut>(wf[ks][tn], xf[ks][tm], acc[tn][tm]);
     __builtin_amdgcn_s_setprio(0);
   };
   auto slot_end = [&]() {
@@ -780,9 +778,12 @@ extern "C" int rpo_debug_set_timeline(unsigned long long* buf) {
 extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return RPO_E_BADARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return RPO_E_BADARG;
-  const bool in_bf16 = a->in_dtype == RPO_BF16, out_bf16 = a->out_dtype == RPO_BF16;
+  // "bf16" below = either 16-bit storage format; a 16-bit output must have the input's format
+  const bool in_f16 = a->in_dtype == RPO_F16, out_f16 = a->out_dtype == RPO_F16;
+  const bool in_bf16 = a->in_dtype == RPO_BF16 || in_f16, out_bf16 = a->out_dtype == RPO_BF16 || out_f16;
   if ((a->in_dtype != RPO_F32 && !in_bf16) || (a->out_dtype != RPO_F32 && !out_bf16)) return RPO_E_DTYPE;
   if (!in_bf16 && out_bf16) return RPO_E_DTYPE;
+  if (out_bf16 && out_f16 != in_f16) return RPO_E_DTYPE;
   const int bk = in_bf16 ? 64 : 32;
   const int esz = in_bf16 ? 2 : 4, osz = out_bf16 ? 2 : 4;
   if (a->K % bk != 0 || a->N % 4 != 0) return RPO_E_SHAPE;
@@ -813,6 +814,10 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (in_f16) {
+    if (out_bf16) return dispatch_epi<f16_t, f16_t>(epi, p, s);
+    return dispatch_f32out<f16_t>(epi, p, s);
+  }
   if (in_bf16) {
     if (out_bf16) return dispatch_epi<bf16_t, bf16_t>(epi, p, s);
     return dispatch_f32out<bf16_t>(epi, p, s);

@@ -316,6 +316,9 @@ extern "C" int rpo_im2col_patches(const float* img, void* out, int out_dtype, in
   if (out_dtype == RPO_BF16)
     hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, img,
                        static_cast<bf16_t*>(out), ldo, B, H, W, patch, total);
+  else if (out_dtype == RPO_F16)
+    hipLaunchKernelGGL(im2col_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, img,
+                       static_cast<f16_t*>(out), ldo, B, H, W, patch, total);
   else if (out_dtype == RPO_F32)
     hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, img,
                        static_cast<float*>(out), ldo, B, H, W, patch, total);
@@ -393,6 +396,9 @@ extern "C" int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dty
   if (dst_dtype == RPO_BF16)
     hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
                        static_cast<bf16_t*>(dst), ldd, rows, cols);
+  else if (dst_dtype == RPO_F16)
+    hipLaunchKernelGGL(convert_kernel<f16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
+                       static_cast<f16_t*>(dst), ldd, rows, cols);
   else if (dst_dtype == RPO_F32)
     hipLaunchKernelGGL(convert_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds,
                        static_cast<float*>(dst), ldd, rows, cols);

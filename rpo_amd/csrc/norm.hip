@@ -73,6 +73,12 @@ template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
                      __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
+template <> __device__ __forceinline__ float4 load4f<f16_t>(const f16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(unpack1<f16_t>((uint16_t)(u.x & 0xffffu)), unpack1<f16_t>((uint16_t)(u.x >> 16)),
+                     unpack1<f16_t>((uint16_t)(u.y & 0xffffu)), unpack1<f16_t>((uint16_t)(u.y >> 16)));
+}
+
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 template <typename TDY, typename TC, int NV>
 __global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
@@ -178,6 +184,9 @@ extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   } else if (y_dtype == RPO_BF16) {
     if (reinterpret_cast<uintptr_t>(y) % 8) return RPO_E_ALIGN;
     RPO_LN_FWD_NV(bf16_t);
+  } else if (y_dtype == RPO_F16) {
+    if (reinterpret_cast<uintptr_t>(y) % 8) return RPO_E_ALIGN;
+    RPO_LN_FWD_NV(f16_t);
   } else {
     return RPO_E_DTYPE;
   }
@@ -211,11 +220,14 @@ extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, con
     else if (nv == 4) RPO_LN_BWD_(TDY, TC, 4); else RPO_LN_BWD_(TDY, TC, 8);                   \
   } while (0)
   const bool cast_bf16 = dx_cast != nullptr && cast_dtype == RPO_BF16;
-  if (dx_cast != nullptr && cast_dtype != RPO_BF16 && cast_dtype != RPO_F32) return RPO_E_DTYPE;
+  const bool cast_f16 = dx_cast != nullptr && cast_dtype == RPO_F16;
+  if (dx_cast != nullptr && cast_dtype != RPO_BF16 && cast_dtype != RPO_F16 && cast_dtype != RPO_F32) return RPO_E_DTYPE;
   if (dy_dtype == RPO_F32) {
-    if (cast_bf16) RPO_LN_BWD(float, bf16_t); else RPO_LN_BWD(float, float);
+    if (cast_bf16) RPO_LN_BWD(float, bf16_t); else if (cast_f16) RPO_LN_BWD(float, f16_t); else RPO_LN_BWD(float, float);
   } else if (dy_dtype == RPO_BF16) {
     if (cast_bf16) RPO_LN_BWD(bf16_t, bf16_t); else RPO_LN_BWD(bf16_t, float);
+  } else if (dy_dtype == RPO_F16) {
+    if (cast_f16) RPO_LN_BWD(f16_t, f16_t); else RPO_LN_BWD(f16_t, float);
   } else {
     return RPO_E_DTYPE;
   }

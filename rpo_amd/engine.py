@@ -67,7 +67,7 @@ class Engine:
             device = torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.dev, self.act = cfg, device, act_dtype
         self.max_batch = max_batch
-        self.kmult = 64 if act_dtype == torch.bfloat16 else 32
+        self.kmult = 32 if act_dtype == torch.float32 else 64
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH, EPI_QGELU_BWD, RPO_BF16,
-                   RPO_F32, GemmArgs, check)
+                   RPO_F16, RPO_F32, GemmArgs, check)
 
 LN_EPS = 1e-5
 
@@ -23,6 +23,8 @@ def dtype_code(t: torch.dtype) -> int:
         return RPO_F32
     if t == torch.bfloat16:
         return RPO_BF16
+    if t == torch.float16:
+        return RPO_F16
     raise TypeError(f"unsupported dtype {t}")
 
 

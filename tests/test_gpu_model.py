@@ -22,6 +22,8 @@ from rpo_amd import synth  # noqa: E402
 TOL_F32 = 1e-3
 BF16_LOGIT_ATOL = 0.12         # logits are O(1..8) at scale 100; measured <= 0.06 (printed by the test)
 BF16_GRAD_REL = 0.05           # relative to max |grad|; measured 2.0-2.3 %
+F16_LOGIT_ATOL = 1e-2          # native IEEE-half storage mode (TRAINER.RPO.PREC = fp16 / amp): 8x finer than bf16
+F16_GRAD_REL = 6e-3
 
 
 def _model(tag, act, max_batch=None):
@@ -113,7 +115,31 @@ def test_bf16_error_is_bounded_and_reported(tag):
     assert (logits.argmax(-1) == g["logits"].argmax(-1)).mean() >= 0.5
 
 
-@pytest.mark.parametrize("act", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["d2_k8_b3", "d2_k16_b2", "d12_k24_b4"])
+def test_f16_mode_matches_reference_golden(tag):
+    """Row f4: the native fp16 storage mode (f16 weights / activations on v_mfma_f32_32x32x16_f16, fp32 accumulate,
+    fp32 residual stream / LayerNorm / softmax / head / optimiser) against the reference goldens at a stated bound:
+    logits within 1e-2 absolute (they are O(1..8)), prompt gradients within 0.6 % of their largest entry."""
+    g = load_golden(tag)
+    m, image, label = _model(tag, torch.float16)
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    m.prompt_learner.train()
+    loss = m(image, label)
+    loss.backward()
+    gt = m.prompt_learner.text_prompt.grad.cpu().numpy()
+    gi = m.prompt_learner.img_prompt.grad.cpu().numpy()
+    le = np.abs(logits - g["logits"]).max()
+    rt, ri = _relmax(gt, g["g_text"]), _relmax(gi, g["g_img"])
+    print(f"[f16 {tag}] logits err {le:.3e} loss err {abs(loss.item() - float(g['loss'])):.3e} "
+          f"g_text rel {rt:.3e} g_img rel {ri:.3e}")
+    assert np.isfinite(logits).all() and le <= F16_LOGIT_ATOL
+    assert abs(loss.item() - float(g["loss"])) <= F16_LOGIT_ATOL
+    assert rt <= F16_GRAD_REL and ri <= F16_GRAD_REL
+    assert (logits.argmax(-1) == g["logits"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("act", [torch.float32, torch.bfloat16, torch.float16])
 def test_graph_replay_equals_eager(act):
     from rpo_amd.trainer import RPO
     tag = "d2_k8_b3"
@@ -297,10 +323,12 @@ def test_edge_shapes_against_oracle_f32(K, n_cls, B):
 
 
 FULL_SIZE = [("ViT-B/16", 24, 32, torch.float32), ("ViT-B/16", 24, 32, torch.bfloat16),
+             ("ViT-B/16", 24, 32, torch.float16),
              ("ViT-B/16", 4, 32, torch.bfloat16), ("ViT-B/16", 8, 32, torch.bfloat16),
              ("ViT-B/16", 16, 32, torch.float32), ("ViT-B/16", 16, 32, torch.bfloat16),
              ("ViT-B/16", 48, 32, torch.bfloat16),
-             ("ViT-L/14", 24, 16, torch.float32), ("ViT-L/14", 24, 16, torch.bfloat16)]
+             ("ViT-L/14", 24, 16, torch.float32), ("ViT-L/14", 24, 16, torch.bfloat16),
+             ("ViT-L/14", 24, 16, torch.float16)]
 
 
 @pytest.mark.parametrize("model,K,B,act", FULL_SIZE, ids=lambda v: str(v).replace("torch.", ""))
@@ -358,7 +386,10 @@ def test_full_size_properties(model, K, B, act):
         rt = (g0.cpu()[:nt] - gf[:nt]).abs().max().item() / gf[:nt].abs().max().item()
         ri = (g0.cpu()[nt:] - gf[nt:]).abs().max().item() / gf[nt:].abs().max().item()
         print(f"[full size {model} K={K} B={B} {act}] vs f32 mode: logits err {le:.3e} g_text rel {rt:.3e} g_img rel {ri:.3e}")
-        assert le <= BF16_LOGIT_ATOL and rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL
+        # (against the goldens the f16 bound is 1e-2, measured 4e-3 .. 9e-3; at B = 32 the largest of 608 logits
+        #  against the f32 MODE reads 1.0e-2, so this cross-check gets twice that)
+        la, gr = (BF16_LOGIT_ATOL, BF16_GRAD_REL) if act == torch.bfloat16 else (2 * F16_LOGIT_ATOL, F16_GRAD_REL)
+        assert le <= la and rt <= gr and ri <= gr
 
 
 _F32_FULL = {}

@@ -1,10 +1,11 @@
 """Op-level parity on the MI355X: every C-ABI kernel against its CPU oracle
-(oracle/rows_oracle.py, float64) on seeded inputs, both storage modes.
+(oracle/rows_oracle.py, float64) on seeded inputs, all three storage modes.
 
 Tolerances (written here, asserted below):
   f32 mode : max|err| <= 2e-5 * max|ref|   (exact-f32 MFMA; only summation order differs)
   bf16 mode: max|err| <= 1.5e-2 * max|ref| (inputs are pre-rounded to bf16 so the error
              budget is the bf16 rounding of outputs / of P inside attention)
+  f16 mode : max|err| <= 2e-3 * max|ref|   (IEEE half: 3 more mantissa bits than bf16)
 """
 import math
 
@@ -16,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import rows_oracle as R  # noqa: E402  (checker only)
 
-DT = {"f32": torch.float32, "bf16": torch.bfloat16}
-TOL = {"f32": 2e-5, "bf16": 1.5e-2}
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+TOL = {"f32": 2e-5, "bf16": 1.5e-2, "f16": 2e-3}
 
 
 def dev():
@@ -62,7 +63,7 @@ def test_library_loads_and_probe_layouts():
         assert torch.equal(d, a @ b.t()), f"MFMA layout probe {which} failed"
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(130, 260, 128), (333, 768, 768), (64, 128, 3072)])
 def test_gemm_epilogues(mode, M, N, K):
     from rpo_amd import _lib as L
@@ -101,7 +102,7 @@ def test_gemm_epilogues(mode, M, N, K):
     close(got[:, :sc], ref[:, :sc], mode, "gemm skip (left)")
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(3000, 3072, 128), (6400, 1024, 128), (2000, 3072, 64), (7072, 3072, 768)])
 def test_gemm_many_tiles_all_epilogues(mode, M, N, K):
     """Multi-round launches (more tiles than resident workgroups) of every tile shape the heuristic picks
@@ -175,40 +176,43 @@ def test_gemm_pingpong_256_bit_identical_and_race_screen(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(7072, 2304, 768), (7072, 3072, 768), (4096, 4096, 128), (2048, 1536, 256),
                                    (7000, 2304, 192), (6500, 2560, 3072), (3000, 2312, 192), (257, 264, 128)])
-def test_gemm_one_wave_per_simd_256_bit_identical_and_race_screen(M, N, K):
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_gemm_one_wave_per_simd_256_bit_identical_and_race_screen(mode, M, N, K):
     """The one-wave-per-SIMD 256x256 kernel (tile_config 8, hand-scheduled asm k-loop): against float64,
     bit-identical to the lock-step 128x128 kernel (same k-order per output), M / N tails, K from 128 (four 32-deep
     tiles: one steady-state iteration + the three-tile tail) upwards, and a race screen -- 25 back-to-back launches
     must all give the same bits."""
     from rpo_amd import _lib as L
     o = ops()
+    if mode == "f16" and K == 3072:
+        pytest.skip("one long-K case per format is enough (CPU reference matmul time)")
     a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
     bias = rnd((N,), 3)
-    acc = q(a, "bf16") @ q(w, "bf16").t()
-    ad, wd, bd = a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), bias.to(dev())
+    acc = q(a, mode) @ q(w, mode).t()
+    ad, wd, bd = a.to(dev(), DT[mode]), w.to(dev(), DT[mode]), bias.to(dev())
     row0 = max(M - 300, 0)
     ref_cfg = 2
     for epi, ref in ((L.EPI_BIAS, acc + bias.double()), (L.EPI_BIAS_QGELU, R.qgelu(acc + bias.double()))):
         outs = {}
         for cfg in (8, ref_cfg):
-            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+            out = torch.full((M, N), float("nan"), dtype=DT[mode], device=dev())
             kw = dict(bias=bd)
             if epi == L.EPI_BIAS_QGELU:
                 kw.update(aux_row0=row0, aux=torch.full((M - row0, N), float("nan"), device=dev()))
             o.gemm_nt(ad, wd, out, epi, tile_config=cfg, **kw)
             outs[cfg] = (out, kw.get("aux"))
-        close(outs[8][0], ref, "bf16", f"w4 gemm epi {epi}")
+        close(outs[8][0], ref, mode, f"w4 gemm epi {epi}")
         assert torch.equal(outs[8][0], outs[ref_cfg][0]), f"tile_config {ref_cfg} differs from the one-wave-per-SIMD kernel"
         if epi == L.EPI_BIAS_QGELU:
             assert torch.equal(outs[8][1], outs[ref_cfg][1])
         if epi == L.EPI_BIAS:
             for _ in range(25):
-                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+                out = torch.empty((M, N), dtype=DT[mode], device=dev())
                 o.gemm_nt(ad, wd, out, epi, tile_config=8, bias=bd)
                 assert torch.equal(out, outs[8][0]), "one-wave-per-SIMD kernel is not deterministic: LDS race"
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_gemm_split_k_feeds_layernorm_bwd(mode):
     """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""
     from rpo_amd import _lib as L
@@ -226,7 +230,7 @@ def test_gemm_split_k_feeds_layernorm_bwd(mode):
     close(dx, ref, "f32", "ln bwd over split-K slabs", tol=2e-5 if mode == "f32" else 2e-4)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("patch,size", [(16, 64), (14, 56)])
 def test_patch_embed_matches_conv(mode, patch, size):
     from rpo_amd import _lib as L
@@ -236,7 +240,7 @@ def test_patch_embed_matches_conv(mode, patch, size):
     npatch = g * g
     img, w = rnd((B, 3, size, size), 1), rnd((d, 3, patch, patch), 2, 0.05)
     pos, cls, prm = rnd((npatch + 1, d), 3), rnd((d,), 4), rnd((5, d), 5)
-    kmult = 64 if mode == "bf16" else 32
+    kmult = 32 if mode == "f32" else 64
     kp = (3 * patch * patch + kmult - 1) // kmult * kmult
     cols = torch.full((B * npatch, kp), float("nan"), dtype=DT[mode], device=dev())
     o.im2col_patches(img.to(dev()), cols, patch)
@@ -260,18 +264,18 @@ def test_layernorm_fwd_bwd(d):
     x, w, b = rnd((rows, d), 1, 2.0) + 0.3, rnd((d,), 2, 0.1) + 1.0, rnd((d,), 3, 0.05)
     dy, dres = rnd((rows, d), 4), rnd((rows, d), 5)
     xd = x.to(dev())
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "f16"):
         y = torch.empty(rows, d, dtype=DT[mode], device=dev())
         o.layernorm_fwd(xd, w.to(dev()), b.to(dev()), y)
         close(y, R.ln_fwd(x.double(), w.double(), b.double()), mode, f"ln fwd d={d}",
-              tol=2e-6 if mode == "f32" else 8e-3)
+              tol={"f32": 2e-6, "bf16": 8e-3, "f16": 1e-3}[mode])
         dyq = dy.to(DT[mode])
         dx = torch.empty(rows, d, device=dev())
         dxc = torch.empty(rows, d, dtype=DT[mode], device=dev())
         o.layernorm_bwd(dyq.to(dev()), xd, w.to(dev()), dres.to(dev()), dx, dxc)
         ref = dres.double() + R.ln_bwd(dyq.double(), x.double(), w.double())
         close(dx, ref, "f32", f"ln bwd d={d} dy={mode}", tol=5e-6)
-        close(dxc, ref, mode, f"ln bwd cast d={d}", tol=5e-6 if mode == "f32" else 8e-3)
+        close(dxc, ref, mode, f"ln bwd cast d={d}", tol={"f32": 5e-6, "bf16": 8e-3, "f16": 1e-3}[mode])
         o.layernorm_bwd(dyq.to(dev()), xd, w.to(dev()), None, dx, None)
         close(dx, R.ln_bwd(dyq.double(), x.double(), w.double()), "f32", "ln bwd no-resid", tol=5e-6)
     # in-place fp32 (ln_pre)
@@ -286,7 +290,7 @@ def _img_rows(B, N, Kp, d, seed):
     return t
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,N,Kp", [(2, 3, 197, 24), (1, 2, 50, 7), (2, 1, 257, 48), (1, 1, 5, 0), (1, 2, 224, 40)])
 def test_attn_readonly_fwd(mode, B, H, N, Kp):
     o = ops()
@@ -308,7 +312,7 @@ def test_attn_readonly_fwd(mode, B, H, N, Kp):
     close(out, ref, mode, f"attn fwd B{B} H{H} N{N} K{Kp}")
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,N,Kp", [(2, 3, 197, 24), (1, 2, 50, 7), (2, 1, 257, 48), (1, 1, 197, 33)])
 def test_attn_readonly_bwd(mode, B, H, N, Kp):
     o = ops()
@@ -329,7 +333,7 @@ def test_attn_readonly_bwd(mode, B, H, N, Kp):
     close(dq, ref, mode, f"attn bwd B{B} H{H} N{N} K{Kp}", tol=None if mode == "f32" else 3e-2)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_text_attn_fwd_bwd(mode):
     o = ops()
     lens = [3, 71, 20, 8, 10]

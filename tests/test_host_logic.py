@@ -263,6 +263,6 @@ def test_prec_mapping():
     import torch
     from rpo_amd.config import act_dtype_for_prec
     assert act_dtype_for_prec("fp32") is torch.float32
-    assert act_dtype_for_prec("fp16") is torch.bfloat16 and act_dtype_for_prec("amp") is torch.bfloat16
+    assert act_dtype_for_prec("fp16") is torch.float16 and act_dtype_for_prec("amp") is torch.float16
     with pytest.raises(ValueError):
         act_dtype_for_prec("int8")
