@@ -220,7 +220,7 @@ def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
     e.synchronize()
     ms = s.elapsed_time(e) / iters
     return {"batch": batch, "ms_per_batch": round(ms, 3), "images_per_sec": round(1e3 * batch / ms, 1),
-            "note": "eager launches (no graph); text tower skipped after the first batch"}
+            "note": "image tower + head replayed as one HIP graph; text features cached after the first batch"}
 
 
 def time_input_pipeline(dev, batch: int, iters: int = 20):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 1
+#define RPO_ABI_VERSION 2
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -61,9 +61,16 @@ enum {
                               >= aux_row0 (the rows that will be back-propagated)   (c_fc, clip/model.py:174-175) */
   RPO_EPI_BIAS_RESID = 3,  /* C(f32) = resid + acc + bias              (out_proj / c_proj + residual, :189-190) */
   RPO_EPI_QGELU_BWD = 4,   /* C = acc * quickgelu'(aux[m,n])           (backward through clip/model.py:162-164) */
-  RPO_EPI_PATCH = 5        /* C(f32)[m + m/group + 1, n] = acc + resid[(m % group) + 1, n]: patch embedding
+  RPO_EPI_PATCH = 5,       /* C(f32)[m + m/group + 1, n] = acc + resid[(m % group) + 1, n]: patch embedding
                               written straight into the token matrix with the positional embedding added
                               (trainers/rpo.py:198-202)                                                      */
+  /* LayerNorm folded into the GEMM that consumes it (clip/model.py:156-159 feeding :186 / :174).  With
+     W'[n,k] = gamma[k] W[n,k], s[n] = sum_k W'[n,k], b'[n] = b[n] + sum_k beta[k] W[n,k]:
+         LN(x) . W^T + b  =  rstd[m] * (x . W'^T - mu[m] * s[n]) + b'[n]
+     so A is the RAW residual row (16-bit copy written by the producing GEMM, `out2` below), W = W', bias = b',
+     ln_colsum = s, and mu / rstd come from the per-row partial statistics the producer left in ln_stats. */
+  RPO_EPI_LN_BIAS = 6,       /* C = LN-fold(acc)                        (ln_1 + in-proj)                     */
+  RPO_EPI_LN_BIAS_QGELU = 7  /* C = quickgelu(LN-fold(acc)), aux as BIAS_QGELU   (ln_2 + c_fc)               */
 };
 
 typedef struct rpo_gemm_args {
@@ -87,6 +94,15 @@ typedef struct rpo_gemm_args {
   int32_t tile_config;           /* 0 = choose by shape; for benchmarking: 2 = 128x128 tiles, 8 = 256x256 one wave per SIMD, 3 = 256x256 (bf16
                                     in/out, BIAS / BIAS_QGELU only, else falls through), 5 = 64x64, 6 = 64x128,
                                     7 = 256x256 ping-pong schedule (same conditions as 3; what 0 picks there) */
+  /* LayerNorm fold (all optional, 0 / NULL = off) */
+  void* out2; int64_t ldout2;    /* BIAS_RESID: also store C in the act dtype (in_dtype) here: the A operand of the
+                                    GEMM that consumes LN(C)                                        */
+  float* ln_stats;               /* BIAS_RESID: OUT, [M][N/64][2] fp32: (mean, sum of squared deviations) of every
+                                    64-column group of the row of C just written (N % 64 == 0).
+                                    LN_BIAS*: IN, the same array for the rows of A (groups = K / 64)  */
+  const float* ln_colsum;        /* LN_BIAS*: s[n], fp32 [N]                                         */
+  float ln_eps;                  /* LN_BIAS*: epsilon of the folded LayerNorm                        */
+  int32_t reserved0;
 } rpo_gemm_args;
 
 int rpo_version(void);

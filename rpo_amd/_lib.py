@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librpo_hip.so")
 
 RPO_F32, RPO_BF16, RPO_F16 = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH = range(6)
+EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH, EPI_LN_BIAS, EPI_LN_BIAS_QGELU = range(8)
 
 c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -43,6 +43,11 @@ class GemmArgs(C.Structure):
         ("split_k", c_i32),
         ("split_stride", c_i64),
         ("tile_config", c_i32),
+        ("out2", c_vp), ("ldout2", c_i64),
+        ("ln_stats", c_vp),
+        ("ln_colsum", c_vp),
+        ("ln_eps", c_f32),
+        ("reserved0", c_i32),
     ]
 
 

@@ -167,11 +167,84 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) loss_b[b] = lb_ok ? (m + logf(s)) - z[lb] : __builtin_nanf("");
 }
 
-__global__ void head_loss_mean_kernel(const float* __restrict__ loss_b, float* loss, int B) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += loss_b[b];
-    *loss = s / (float)B;
+// Forward side of the head in ONE launch for class sets that fit a block (C <= 128; the Oxford-Pets base split has 19):
+// block b = image b.  Phase 1: its K image rows are normalised (unit rows -> LDS and ws for the backward).  Phase 2:
+// wave w owns classes w, w+4, ...; per (class, pair) one pass over e computes <img_unit, text> and |text|^2 with
+// wave shuffles only; block 0 also leaves the unit text rows / inverse norms for the backward.  Phase 3: wave 0 turns
+// the C logits of the image into its CE loss and dl row.  (The mean over the batch is taken by block 0 of
+// head_bwd_kernel: the kernel boundary is the only cross-block ordering needed.)
+__global__ __launch_bounds__(256) void head_fwd_fused_kernel(const float* __restrict__ f_img, const float* __restrict__ f_txt,
+                                                             const int64_t* __restrict__ label, float* ih, float* ni,
+                                                             float* th, float* nt, float* logits, float* dl, float* loss_b,
+                                                             int C, int K, int e, float mul, float gmul) {
+  extern __shared__ __attribute__((aligned(16))) char head_smem[];
+  float* img_u = reinterpret_cast<float*>(head_smem);            // [K][e] unit rows of this image
+  float* lg = img_u + (int64_t)K * e;                            // [C]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = e / 256;                                        // float4 per lane per row (e % 256 == 0)
+  for (int i = wave; i < K; i += 4) {
+    const float* x = f_img + ((int64_t)b * K + i) * e;
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nv) {
+        v[j] = *reinterpret_cast<const float4*>(x + j * 256 + lane * 4);
+        ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+      }
+    const float inv = 1.0f / sqrtf(wave_sum(ss));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nv) {
+        const float4 u = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+        *reinterpret_cast<float4*>(img_u + i * e + j * 256 + lane * 4) = u;
+        *reinterpret_cast<float4*>(ih + ((int64_t)b * K + i) * e + j * 256 + lane * 4) = u;
+      }
+    if (lane == 0) ni[(int64_t)b * K + i] = inv;
+  }
+  __syncthreads();
+  for (int c = wave; c < C; c += 4) {
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i) {
+      const float* t = f_txt + ((int64_t)c * K + i) * e;
+      float4 v[4];
+      float dot = 0.f, ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nv) {
+          v[j] = *reinterpret_cast<const float4*>(t + j * 256 + lane * 4);
+          const float4 u = *reinterpret_cast<const float4*>(img_u + i * e + j * 256 + lane * 4);
+          dot += v[j].x * u.x + v[j].y * u.y + v[j].z * u.z + v[j].w * u.w;
+          ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+      dot = wave_sum(dot);
+      const float inv = 1.0f / sqrtf(wave_sum(ss));
+      acc += dot * inv;
+      if (b == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nv)
+            *reinterpret_cast<float4*>(th + ((int64_t)c * K + i) * e + j * 256 + lane * 4) =
+                make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+        if (lane == 0) nt[(int64_t)c * K + i] = inv;
+      }
+    }
+    if (lane == 0) { lg[c] = acc * mul; logits[(int64_t)b * C + c] = acc * mul; }
+  }
+  if (label == nullptr) return;
+  __syncthreads();
+  if (wave == 0) {                                               // C <= 128: two logits per lane
+    const float z0 = lane < C ? lg[lane] : -INFINITY, z1 = lane + 64 < C ? lg[lane + 64] : -INFINITY;
+    const float m = wave_max(fmaxf(z0, z1));
+    const float e0 = lane < C ? expf(z0 - m) : 0.f, e1 = lane + 64 < C ? expf(z1 - m) : 0.f;
+    const float ssum = wave_sum(e0 + e1);
+    const int64_t lb64 = label[b];                               // out of range: NaN loss, no out-of-bounds access
+    const bool lb_ok = lb64 >= 0 && lb64 < C;
+    const int lb = lb_ok ? (int)lb64 : -1;
+    const float inv = 1.0f / ssum;
+    if (lane < C) dl[(int64_t)b * C + lane] = (e0 * inv - (lane == lb ? 1.0f : 0.0f)) * gmul;
+    if (lane + 64 < C) dl[(int64_t)b * C + lane + 64] = (e1 * inv - (lane + 64 == lb ? 1.0f : 0.0f)) * gmul;
+    if (lane == 0) loss_b[b] = lb_ok ? (m + logf(ssum)) - lg[lb] : __builtin_nanf("");
   }
 }
 
@@ -182,8 +255,13 @@ __global__ void head_loss_mean_kernel(const float* __restrict__ loss_b, float* l
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ ih,
                                                        const float* __restrict__ ni, const float* __restrict__ th,
                                                        const float* __restrict__ nt, float* d_img_f, float* d_text_f,
-                                                       int B, int C, int K, int e) {
+                                                       int B, int C, int K, int e, const float* loss_b, float* loss) {
   __shared__ float red[4];
+  if (loss != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    // mean CE over the batch, fixed summation order
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += loss_b[b];
+    *loss = s / (float)B;
+  }
   const bool img = (int)blockIdx.x < B * K;
   const int row = img ? blockIdx.x : blockIdx.x - B * K;            // g*K + i
   const int g = row / K, i = row % K;
@@ -367,15 +445,25 @@ extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const i
   float* nt = ni + (int64_t)B * K;
   float* dl = nt + (int64_t)C * K;
   float* lb = dl + (int64_t)B * C;
+  const float gmul = scale_exp / ((float)K * (float)B);
+  // Small class sets (the few-shot base / new splits): the whole forward side in one launch, two launches per
+  // training step.  Larger ones (ImageNet: 500 / 1000 classes) spread the logits over (class group, image) blocks.
+  const size_t fused_lds = ((size_t)K * e + C) * sizeof(float);
+  if (C <= 128 && e % 256 == 0 && fused_lds <= 64 * 1024) {
+    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(B), dim3(256), fused_lds, s, img_f, text_f, label, ih, ni, th, nt,
+                       logits, dl, lb, C, K, e, scale_exp / (float)K, gmul);
+    if (label)
+      hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K + C * K), dim3(256), 0, s, dl, ih, ni, th, nt, d_img_f, d_text_f,
+                         B, C, K, e, lb, loss);
+    return rpo_launch_status();
+  }
   hipLaunchKernelGGL(head_normalize_kernel, dim3(B * K + C * K), dim3(256), 0, s, img_f, ih, ni, B * K, text_f, th, nt, e);
   hipLaunchKernelGGL(head_logits_kernel, dim3((C + HEAD_CPB - 1) / HEAD_CPB, B), dim3(256), 0, s, ih, th, logits, C, K * e,
                      scale_exp / (float)K);
   if (label) {
-    const float gmul = scale_exp / ((float)K * (float)B);
     hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
-    hipLaunchKernelGGL(head_loss_mean_kernel, dim3(1), dim3(64), 0, s, lb, loss, B);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K + C * K), dim3(256), 0, s, dl, ih, ni, th, nt, d_img_f, d_text_f,
-                       B, C, K, e);
+                       B, C, K, e, lb, loss);
   }
   return rpo_launch_status();
 }

@@ -48,10 +48,15 @@ def version() -> int:
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
             aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
-            group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0) -> torch.Tensor:
+            group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0,
+            out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
+            ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
-    ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer."""
+    ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
+    LayerNorm fold: a BIAS_RESID call may also leave ``out2`` (act-dtype copy of its result) and ``ln_stats``
+    ([M, N/64, 2] partial row statistics); an LN_BIAS / LN_BIAS_QGELU call reads such ``ln_stats`` for its A rows
+    together with ``ln_colsum`` (see include/rpo_amd.h)."""
     M = a.shape[0] if m_rows is None else m_rows
     N, K = w.shape
     assert a.shape[1] == K and a.dtype == w.dtype
@@ -66,7 +71,13 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     epilogue=epilogue, bias=_p(bias), resid=_p(resid), ldr=0 if resid is None else _ld(resid),
                     aux=_p(aux), ldaux=0 if aux is None else _ld(aux), aux_row0=aux_row0,
                     skip_row0=skip_row0, skip_col0=skip_col0, group=group, split_k=split_k,
-                    split_stride=split_stride, tile_config=tile_config)
+                    split_stride=split_stride, tile_config=tile_config,
+                    out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
+                    ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
+    if ln_stats is not None:
+        rows = a.shape[0] if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else M
+        cols = K if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else N
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= rows * (cols // 64) * 2
     check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
     return out
 

@@ -158,6 +158,26 @@ def test_graph_replay_equals_eager(act):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_eval_graph_equals_eager_and_tracks_prompt_updates():
+    """The eval branch (trainers/rpo.py:229-232) replays a captured graph per batch size: same bits as eager
+    launches, per-image results independent of the batch they came in, and fresh text features after the prompts
+    change."""
+    m, image, label = _model("d2_k8_b3", torch.bfloat16)
+    m.prompt_learner.eval()
+    eng = m.engine
+    a = eng.forward_eval(image, use_graph=False).clone()
+    b = eng.forward_eval(image).clone()
+    c = eng.forward_eval(image).clone()
+    assert torch.equal(a, b) and torch.equal(b, c)
+    b2 = eng.forward_eval(image[:2].contiguous()).clone()
+    assert torch.equal(b2, a[:2]) and set(eng._eval_graphs) == {3, 2}
+    with torch.no_grad():
+        m.prompt_learner.text_prompt.add_(0.01)
+    d = m(image)
+    e = eng.forward_eval(image, use_graph=False).clone()
+    assert torch.equal(d, e) and not torch.equal(d, a)
+
+
 def test_ragged_and_max_length_classes_f32():
     """len_c from 3 up to the maximum 77-K, 5 classes; vs the dense CPU oracle."""
     from oracle.rpo_oracle import OracleRPO
