@@ -47,7 +47,15 @@ struct GemmParams {
   int skip_row0, skip_col0, group;
   int split_k; int64_t split_stride;   // elements of C between slabs
   int force_cfg;                       // 0 = heuristic; 2/3/5/6 force a tile shape (benchmarking)
+  // LayerNorm fold (include/rpo_amd.h, RPO_EPI_LN_*): producer side = out2 + ln_stats (written), consumer side =
+  // ln_stats (read) + ln_colsum
+  char* out2; int64_t ldout2;
+  float* ln_stats;
+  const float* ln_colsum;
+  float ln_eps;
 };
+
+constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic
 
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
 
@@ -191,7 +199,45 @@ __device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0,
   }
 }
 
-template <typename TOut, int EPI, typename CF>
+// LayerNorm fold, consumer side: (mu, rstd) of the tile's A rows from the producer's 64-column partials (mean_g, M2_g),
+// combined the numerically safe way (Chan): mu = mean of means, M2 = sum M2_g + 64 (mean_g - mu)^2.  One row per
+// thread; the result is parked behind the ring / staging image, which nothing else touches, and is read in the
+// epilogue (behind a barrier).  Called before the k-loop so that the two dependent global round trips are hidden.
+// (sum of group means, sum of group M2, sum of squared group means) -> (mu, rstd); every operation spelled out so that
+// all kernels produce the same bits
+__device__ __forceinline__ float2 ln_finish(float mu_sum, float m2_sum, float sq_sum, int G, int K, float eps) {
+  const float mu = mu_sum / (float)G;
+  const float between = fmaxf(fmaf(-(float)G * mu, mu, sq_sum), 0.f);
+  const float m2 = fmaf((float)LN_GROUP, between, m2_sum);
+  return make_float2(mu, rsqrtf(m2 / (float)K + eps));
+}
+template <typename CF>
+__device__ __forceinline__ void ln_row_stats(const GemmParams& p, char* smem, int m0) {
+  float2* row_stats = reinterpret_cast<float2*>(smem + CF::SMEM);
+  const int G = p.K / LN_GROUP;
+  for (int r = threadIdx.x; r < CF::BM; r += CF::THREADS) {
+    const float2* ps = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)min(m0 + r, p.M - 1) * G;
+    float mu = 0.f, m2 = 0.f, sq = 0.f;
+    // single pass: sum of means, sum of M2, sum of squared means (the between-group term is
+    // sum (mean_g - mu)^2 = sum mean_g^2 - G mu^2; the means of 64-column groups are O(1), no cancellation issue).
+    // All loads of a row are issued before the first is used (a load-use loop costs one L2 round trip per group:
+    // 12 in a row were +5 us on c_fc); groups beyond G are clamped loads that the sums mask out.
+    for (int g0 = 0; g0 < G; g0 += 16) {
+      float2 v[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v[g] = ps[min(g0 + g, G - 1)];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float mg = g0 + g < G ? v[g].x : 0.f;
+        mu += mg; m2 += g0 + g < G ? v[g].y : 0.f; sq = fmaf(mg, mg, sq);
+      }
+    }
+    row_stats[r] = ln_finish(mu, m2, sq, G, p.K, p.ln_eps);
+  }
+}
+
+// TAct = the storage type of the activations (= TIn): what a BIAS_RESID epilogue writes its second copy in
+template <typename TOut, int EPI, typename CF, typename TAct = TOut>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[CF::WN_T][CF::WM_T], char* smem,
                                               const int m0, const int n0, const float4* pre = nullptr,
                                               const float4* pre_bias = nullptr) {
@@ -211,27 +257,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   //   otherwise: tile staged as fp32, bias / residual / QuickGELU applied in the row-major pass
   constexpr bool PRECONV = CF::PRECONV_EPI;
   constexpr int CROW = CF::CROW_BYTES(PRECONV);
-  constexpr bool HAS_BIAS = EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID;
-  __builtin_amdgcn_s_barrier();              // everybody is done reading the last stage
+  constexpr bool IS_LN = EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU;
+  constexpr bool IS_QG = EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_LN_BIAS_QGELU;
+  constexpr bool HAS_BIAS = EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID || IS_LN;
+  // LayerNorm fold, consumer side: (mu, rstd) of this tile's A rows were parked behind the staging image by
+  // ln_row_stats() at the start of the kernel (their global round trips hide under the k-loop);
+  // v = rstd * (acc - mu * s[n]) + b'[n] below.
+  const float2* row_stats = reinterpret_cast<const float2*>(smem + CF::SMEM);
+  if constexpr (IS_LN) __syncthreads();      // (also: everybody is done reading the last stage)
+  else __builtin_amdgcn_s_barrier();         // everybody is done reading the last stage
   if constexpr (PRECONV) {
     const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
 #pragma unroll
     for (int tn = 0; tn < CF::WN_T; ++tn) {      // tn outermost: 4 bias quads live at a time (the one-wave-per-SIMD
-      float4 bias_r[4];                          // kernel arrives here with 256 accumulators)
+      float4 bias_r[4], sum_r[4];                // kernel arrives here with 256 accumulators)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
         bias_r[g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (IS_LN) sum_r[g] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nb + tn * 32 + 8 * g, p.N - 4));
+      }
 #pragma unroll
-      for (int tm = 0; tm < CF::WM_T; ++tm)
+      for (int tm = 0; tm < CF::WM_T; ++tm) {
+        float2 st = make_float2(0.f, 1.f);
+        if constexpr (IS_LN) st = row_stats[wm * (CF::WM_T * 32) + tm * 32 + l31];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
           const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
           const float4 b4 = bias_r[g];
-          float4 v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
-                                 acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
-          if (EPI == RPO_EPI_BIAS_QGELU) {
+          float4 v;
+          if constexpr (IS_LN) {
+            const float4 s4 = sum_r[g];
+            v = make_float4(fmaf(st.y, acc[tn][tm][4 * g] - st.x * s4.x, b4.x), fmaf(st.y, acc[tn][tm][4 * g + 1] - st.x * s4.y, b4.y),
+                            fmaf(st.y, acc[tn][tm][4 * g + 2] - st.x * s4.z, b4.z), fmaf(st.y, acc[tn][tm][4 * g + 3] - st.x * s4.w, b4.w));
+          } else {
+            v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
+                            acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
+          }
+          if (IS_QG) {
             const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
             if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
               *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
@@ -241,6 +305,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
                 make_uint2(pack2<TOut>(v.x, v.y), pack2<TOut>(v.z, v.w));
         }
+      }
     }
     __syncthreads();
     constexpr int CPR = BN / 8;                       // 16-B chunks per row
@@ -274,9 +339,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     const int cc = tid % CPR, r0 = tid / CPR;
     const int n = n0 + cc * 4;
     const bool nok = n < p.N;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_BIAS && pre_bias != nullptr) b4 = *pre_bias;           // fetched before the main loop
     else if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    if (IS_LN && nok) s4 = *reinterpret_cast<const float4*>(p.ln_colsum + n);
     TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
     for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
       float4 ex[UNR];
@@ -306,8 +372,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         const int row = (pass0 + u) * RPP + r0;
         const int m = m0 + row;
         float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        if (EPI == RPO_EPI_BIAS_QGELU) {
+        if constexpr (IS_LN) {
+          const float2 st = row_stats[row];
+          v.x = fmaf(st.y, v.x - st.x * s4.x, b4.x); v.y = fmaf(st.y, v.y - st.x * s4.y, b4.y);
+          v.z = fmaf(st.y, v.z - st.x * s4.z, b4.z); v.w = fmaf(st.y, v.w - st.x * s4.w, b4.w);
+        } else {
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (IS_QG) {
           if (ok[u] && p.aux != nullptr && m >= p.aux_row0)
             *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
           v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
@@ -320,6 +392,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
         }
         if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
+        if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TAct) == 2) {
+          // LayerNorm fold, producer side: the 16-bit copy the consuming GEMM reads as its A operand, and the
+          // (mean, sum of squared deviations) of each 64-column group of the row: 16 consecutive lanes hold one group
+          if (p.out2 != nullptr && ok[u])
+            ActIO<TAct>::st4(reinterpret_cast<TAct*>(p.out2) + orow[u] * p.ldout2 + n, v.x, v.y, v.z, v.w);
+          if (p.ln_stats != nullptr) {
+            const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+            const float mean = sm * (1.0f / LN_GROUP);
+            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+            const float q = row16_sum((dx * dx + dy * dy) + (dz * dz + dw * dw));
+            if (ok[u] && (cc & 15) == 0)
+              reinterpret_cast<float2*>(p.ln_stats)[orow[u] * (p.N / LN_GROUP) + (n >> 6)] = make_float2(mean, q);
+          }
+        }
       }
     }
   }
@@ -397,9 +483,11 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) dma(s, s);
+  if constexpr (EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU) ln_row_stats<CF>(p, smem, m0);
   // bias of this thread's 4 output columns (row-major epilogue pass), fetched now so its latency hides in the k-loop
   float4 pre_b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (!CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID)) {
+  if constexpr (!CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_BIAS_RESID ||
+                                     EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU)) {
     const int n = n0 + (tid % (CF::BN / 4)) * 4;
     if (n < p.N) pre_b = *reinterpret_cast<const float4*>(p.bias + n);
   }
@@ -479,8 +567,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 
 
   RPO_STAMP(60);
-  gemm_epilogue<TOut, EPI, CF>(p, acc, smem, m0, n0, pre,
-                               CF::PRECONV_EPI ? nullptr : &pre_b);
+  gemm_epilogue<TOut, EPI, CF, TIn>(p, acc, smem, m0, n0, pre,
+                                    CF::PRECONV_EPI ? nullptr : &pre_b);
 #ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -623,6 +711,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 #define PP_T0() do { } while (0)
 #define PP_ACC(v) do { } while (0)
 #endif
+  if constexpr (EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU) ln_row_stats<CF>(p, smem, m0);
   if (wm == 0) {
     // prologue: tiles 0, 1 in flight; tile 0 retired before the barrier that opens slot 0
     if (0 < nk) dma(0);
@@ -689,9 +778,10 @@ template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
   static unsigned long long lds_ok = 0;
   auto kern = gemm_pp_kernel<TOut, EPI>;
-  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), CfgPP::SMEM, &lds_ok)) return rc;
+  constexpr int smem_bytes = CfgPP::SMEM + CfgPP::BM * 8;     // + (mu, rstd) per row of the LayerNorm-fold epilogues
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), smem_bytes, &lds_ok)) return rc;
   const int tiles = ((p.M + CfgPP::BM - 1) / CfgPP::BM) * ((p.N + CfgPP::BN - 1) / CfgPP::BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, 1), dim3(CfgPP::THREADS), CfgPP::SMEM, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1), dim3(CfgPP::THREADS), smem_bytes, s, p);
   return rpo_launch_status();
 }
 
@@ -699,9 +789,10 @@ template <typename TIn, typename TOut, int EPI, typename CF>
 int launch_cfg(const GemmParams& p, hipStream_t s) {
   static unsigned long long lds_ok = 0;
   auto kern = gemm_nt_kernel<TIn, TOut, EPI, CF>;
-  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), CF::SMEM, &lds_ok)) return rc;
+  constexpr int smem_bytes = CF::SMEM + CF::BM * 8;           // + (mu, rstd) per row of the LayerNorm-fold epilogues
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), smem_bytes, &lds_ok)) return rc;
   const int tiles = ((p.M + CF::BM - 1) / CF::BM) * ((p.N + CF::BN - 1) / CF::BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, p.split_k), dim3(CF::THREADS), CF::SMEM, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, p.split_k), dim3(CF::THREADS), smem_bytes, s, p);
   return rpo_launch_status();
 }
 
@@ -710,7 +801,8 @@ template <typename TIn, typename TOut, int EPI>
 int launch(const GemmParams& p, hipStream_t s) {
   // measured (tools/bench_gemm.py, profiles/): 256x256 wins for the wide-N forward GEMMs of the image tower
   // (in-proj 31.6 vs 36.1 us); a 4-stage 128x128 variant was slower than 2 stages on every shape
-  constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 && (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU);
+  constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 &&
+                          (EPI == RPO_EPI_BIAS || EPI == RPO_EPI_BIAS_QGELU || EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU);
   if constexpr (big_ok) {
     // one 256x256 workgroup per CU: only worth it when the tiles fill whole rounds of the 256 CUs
     // (in-proj at B=32: 252 tiles; c_fc: 336 tiles = 1.3 rounds -> 65 us vs 55 us with 128x128; ViT-L/14 in-proj at
@@ -726,7 +818,8 @@ int launch(const GemmParams& p, hipStream_t s) {
     // k-tiles.  Bit-identical to the ping-pong kernel (tile_config 7) and the lock-step 256x256 one (3) and faster
     // than both (in-proj at B=32: 28.1 vs 34.3 / 29.5 us on one box), so it is what the heuristic picks.
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
-    const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK;
+    constexpr bool epi_ln = EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU;
+    const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK && (!epi_ln || p.K <= 16 * LN_GROUP);
     const bool wants_big = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills;
     if (w4_ok && (p.force_cfg == 8 || wants_big)) return launch_w4<TOut, EPI>(p, s);
     if (ok && (p.force_cfg == 7 || wants_big)) return launch_pp<TOut, EPI>(p, s);
@@ -753,6 +846,12 @@ int dispatch_epi(int epi, const GemmParams& p, hipStream_t s) {
     case RPO_EPI_BIAS: return launch<TIn, TOut, RPO_EPI_BIAS>(p, s);
     case RPO_EPI_BIAS_QGELU: return launch<TIn, TOut, RPO_EPI_BIAS_QGELU>(p, s);
     case RPO_EPI_QGELU_BWD: return launch<TIn, TOut, RPO_EPI_QGELU_BWD>(p, s);
+    case RPO_EPI_LN_BIAS:
+      if constexpr (sizeof(TOut) == 2) return launch<TIn, TOut, RPO_EPI_LN_BIAS>(p, s);
+      return RPO_E_DTYPE;
+    case RPO_EPI_LN_BIAS_QGELU:
+      if constexpr (sizeof(TOut) == 2) return launch<TIn, TOut, RPO_EPI_LN_BIAS_QGELU>(p, s);
+      return RPO_E_DTYPE;
     default: return RPO_E_DTYPE;
   }
 }
@@ -791,12 +890,21 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
     return RPO_E_ALIGN;
   if ((reinterpret_cast<uintptr_t>(a->C) % (4 * osz)) != 0 || (a->ldc * osz) % (4 * osz) != 0) return RPO_E_ALIGN;
   const int epi = a->epilogue;
-  const bool needs_bias = epi == RPO_EPI_BIAS || epi == RPO_EPI_BIAS_QGELU || epi == RPO_EPI_BIAS_RESID;
+  const bool is_ln = epi == RPO_EPI_LN_BIAS || epi == RPO_EPI_LN_BIAS_QGELU;
+  const bool needs_bias = epi == RPO_EPI_BIAS || epi == RPO_EPI_BIAS_QGELU || epi == RPO_EPI_BIAS_RESID || is_ln;
+  if (is_ln && (!out_bf16 || a->ln_stats == nullptr || a->ln_colsum == nullptr || !aligned16(a->ln_colsum) ||
+                reinterpret_cast<uintptr_t>(a->ln_stats) % 8 != 0 || !(a->ln_eps > 0.0f))) return RPO_E_BADARG;
+  if (!is_ln && epi != RPO_EPI_BIAS_RESID && (a->ln_stats != nullptr || a->out2 != nullptr)) return RPO_E_BADARG;
+  if (epi == RPO_EPI_BIAS_RESID && (a->ln_stats != nullptr || a->out2 != nullptr)) {
+    if (!in_bf16 || a->N % 64 != 0) return RPO_E_SHAPE;
+    if (a->out2 != nullptr && (reinterpret_cast<uintptr_t>(a->out2) % 8 != 0 || (a->ldout2 * 2) % 8 != 0)) return RPO_E_ALIGN;
+    if (a->ln_stats != nullptr && reinterpret_cast<uintptr_t>(a->ln_stats) % 8 != 0) return RPO_E_ALIGN;
+  }
   if (needs_bias && (a->bias == nullptr || !aligned16(a->bias))) return RPO_E_BADARG;
   if ((epi == RPO_EPI_BIAS_RESID || epi == RPO_EPI_PATCH) &&
       (a->resid == nullptr || !aligned16(a->resid) || a->ldr % 4 != 0 || out_bf16)) return RPO_E_BADARG;
   if (epi == RPO_EPI_QGELU_BWD && a->aux == nullptr) return RPO_E_BADARG;
-  if ((epi == RPO_EPI_QGELU_BWD || (epi == RPO_EPI_BIAS_QGELU && a->aux != nullptr)) &&
+  if ((epi == RPO_EPI_QGELU_BWD || ((epi == RPO_EPI_BIAS_QGELU || epi == RPO_EPI_LN_BIAS_QGELU) && a->aux != nullptr)) &&
       (!aligned16(a->aux) || a->ldaux % 4 != 0)) return RPO_E_ALIGN;
   if (epi == RPO_EPI_PATCH && a->group <= 0) return RPO_E_BADARG;
 
@@ -811,6 +919,8 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.split_k = a->split_k <= 1 ? 1 : a->split_k;
   p.split_stride = a->split_stride;
   p.force_cfg = a->tile_config;
+  p.out2 = static_cast<char*>(a->out2); p.ldout2 = a->ldout2;
+  p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);

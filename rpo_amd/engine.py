@@ -26,7 +26,10 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE, EPI_PATCH, EPI_QGELU_BWD
+import os
+
+from ._lib import (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_LN_BIAS, EPI_LN_BIAS_QGELU, EPI_NONE, EPI_PATCH,
+                   EPI_QGELU_BWD)
 from .config import RPOConfig
 
 import contextlib
@@ -54,6 +57,10 @@ class _Block:
     w_out_t: torch.Tensor                           # [d, d]
     w_fc_t: torch.Tensor                            # [d, 4d]
     w_proj_t: torch.Tensor                          # [4d, d]
+    # LayerNorm folded into the consuming GEMM (include/rpo_amd.h RPO_EPI_LN_*; image tower, 16-bit modes):
+    # W' = gamma o W (act dtype), s = row sums of the ROUNDED W', b' = b + W beta
+    w_in_ln: Optional[torch.Tensor] = None; s_in: Optional[torch.Tensor] = None; b_in_ln: Optional[torch.Tensor] = None
+    w_fc_ln: Optional[torch.Tensor] = None; s_fc: Optional[torch.Tensor] = None; b_fc_ln: Optional[torch.Tensor] = None
 
 
 class Engine:
@@ -68,6 +75,9 @@ class Engine:
         self.cfg, self.dev, self.act = cfg, device, act_dtype
         self.max_batch = max_batch
         self.kmult = 32 if act_dtype == torch.float32 else 64
+        # ln_1 / ln_2 of the image blocks ride in the epilogues of the GEMMs around them (16-bit modes; the f32 parity
+        # mode keeps the stand-alone LayerNorm kernels, bit for bit what the goldens were validated with)
+        self.fold_ln = act_dtype != torch.float32 and os.environ.get("RPO_NO_LN_FOLD") != "1"
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -96,20 +106,35 @@ class Engine:
         out = torch.empty(w.shape, dtype=self.act, device=self.dev)
         return ops.convert(w, out)
 
-    def _block(self, sd, p: str) -> _Block:
+    def _fold(self, w: np.ndarray, b: np.ndarray, gamma: np.ndarray, beta: np.ndarray):
+        """(W', s, b') of the LayerNorm fold, computed on the host: W' is rounded to the act dtype exactly as the
+        device would (RNE) and s sums the ROUNDED values, so that mu * s cancels what the MFMA really accumulates."""
+        w64, g64 = np.asarray(w, dtype=np.float64), np.asarray(gamma, dtype=np.float64)
+        wq = torch.from_numpy((w64 * g64[None, :]).astype(np.float32)).to(self.act)
+        s = wq.double().sum(1).float()
+        bq = torch.from_numpy((np.asarray(b, dtype=np.float64) + w64 @ np.asarray(beta, dtype=np.float64)).astype(np.float32))
+        return wq.contiguous().to(self.dev), s.contiguous().to(self.dev), bq.contiguous().to(self.dev)
+
+    def _block(self, sd, p: str, fold: bool = False) -> _Block:
         g = lambda k: self._f32(sd[p + k])
         w_in, w_out, w_fc, w_proj = g("attn.in_proj_weight"), g("attn.out_proj.weight"), g("mlp.c_fc.weight"), g("mlp.c_proj.weight")
         d = w_out.shape[0]
-        return _Block(
+        extra = {}
+        if fold:
+            extra["w_in_ln"], extra["s_in"], extra["b_in_ln"] = self._fold(
+                sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"], sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+            extra["w_fc_ln"], extra["s_fc"], extra["b_fc_ln"] = self._fold(
+                sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+        return _Block(**extra, **dict(
             ln1_w=g("ln_1.weight"), ln1_b=g("ln_1.bias"), ln2_w=g("ln_2.weight"), ln2_b=g("ln_2.bias"),
             w_in=self._act(w_in), b_in=g("attn.in_proj_bias"), w_out=self._act(w_out), b_out=g("attn.out_proj.bias"),
             w_fc=self._act(w_fc), b_fc=g("mlp.c_fc.bias"), w_proj=self._act(w_proj), b_proj=g("mlp.c_proj.bias"),
             w_q_t=self._act(w_in[:d].t()), w_out_t=self._act(w_out.t()), w_fc_t=self._act(w_fc.t()),
-            w_proj_t=self._act(w_proj.t()))
+            w_proj_t=self._act(w_proj.t())))
 
     def _pack(self, sd, tokens) -> None:
         cfg = self.cfg
-        self.vis = [self._block(sd, f"visual.transformer.resblocks.{l}.") for l in range(cfg.layers_v)]
+        self.vis = [self._block(sd, f"visual.transformer.resblocks.{l}.", fold=self.fold_ln) for l in range(cfg.layers_v)]
         self.txt = [self._block(sd, f"transformer.resblocks.{l}.") for l in range(cfg.layers_t)]
         self.kpatch = _round_up(cfg.patch_dim, self.kmult)
         conv = torch.zeros(cfg.d_v, self.kpatch, device=self.dev)
@@ -140,6 +165,7 @@ class Engine:
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
         self.h = a(R, dv)
+        self.ln_stats = f32(R, dv // 64, 2)          # per-row partial LayerNorm statistics of the tensor self.h copies
         self.qkv = [a(R, 3 * dv) for _ in range(Lv)]
         self.att = a(R, dv)
         self.g = a(R, 4 * dv)
@@ -259,14 +285,23 @@ class Engine:
         ops.img_assemble(x_pre, self.cls, self.pos, self.img_prompt, B, N, K)          # rpo.py:201-204
         ops.layernorm_fwd(x_pre, self.ln_pre[0], self.ln_pre[1], self.x[0][:R])        # rpo.py:206
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
+        st = self.ln_stats[:R]
+        fold = self.fold_ln
         last = len(self.vis) - 1
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
-            ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
+            # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
+            # left by the previous block's c_proj; the GEMM epilogue applies the normalisation (RPO_EPI_LN_BIAS).
+            folded_in = fold and l > 0
+            if not folded_in:
+                ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
+            w_in, b_in = (blk.w_in_ln, blk.b_in_ln) if folded_in else (blk.w_in, blk.b_in)
+            epi_in = EPI_LN_BIAS if folded_in else EPI_BIAS
+            lnk = lambda r0, r1, c0, c1: (dict(ln_stats=st[r0:r1], ln_colsum=blk.s_in[c0:c1]) if folded_in else {})
             if l < last:
                 # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
                 with self._timed("in_proj"):
-                    ops.gemm_nt(h, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in, skip_row0=Rf, skip_col0=dv)
+                    ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv))
                 with self._timed("attn_fwd"):
                     ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
                 lo = 0
@@ -274,21 +309,31 @@ class Engine:
                 # Last block: only its K prompt rows are consumed (ln_post reads x[:, -K:], rpo.py:210; the CLS feature
                 # i_f of :211 is dead code), and no later block reads the frozen rows.  So the frozen rows contribute
                 # their K / V and nothing else: q and everything after attention run on the B*K prompt rows only.
-                ops.gemm_nt(h[:Rf], blk.w_in[dv:], qkv[:Rf, dv:], EPI_BIAS, bias=blk.b_in[dv:])
-                ops.gemm_nt(h[Rf:], blk.w_in[:dv], qkv[Rf:, :dv], EPI_BIAS, bias=blk.b_in[:dv])
+                ops.gemm_nt(h[:Rf], w_in[dv:], qkv[:Rf, dv:], epi_in, bias=b_in[dv:], **lnk(0, Rf, dv, 3 * dv))
+                ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv))
                 ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE,
                                       q_first=N)
                 lo = Rf
             timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
+            # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
+            prod = dict(out2=h[lo:], ln_stats=st[lo:]) if fold else {}
             with timed("out_proj"):
-                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:])
-            with timed("ln_2"):
-                ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
-            with timed("c_fc"):
-                ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
-                            aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
+                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:], **prod)
+            if fold:
+                with timed("c_fc"):
+                    ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo,
+                                ln_stats=st[lo:], ln_colsum=blk.s_fc)
+            else:
+                with timed("ln_2"):
+                    ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
+                with timed("c_fc"):
+                    ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
+                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
+            # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
+            prod = dict(out2=h[lo:], ln_stats=st[lo:]) if (fold and l < last) else {}
             with timed("c_proj"):
-                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:])
+                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:], **prod)
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

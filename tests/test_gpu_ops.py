@@ -212,6 +212,55 @@ def test_gemm_one_wave_per_simd_256_bit_identical_and_race_screen(mode, M, N, K)
                 assert torch.equal(out, outs[8][0]), "one-wave-per-SIMD kernel is not deterministic: LDS race"
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("M,d,N", [(300, 768, 3072), (4200, 768, 2304), (1000, 1024, 4096)])
+def test_gemm_layernorm_fold(mode, M, d, N):
+    """LayerNorm folded into the GEMM around it (include/rpo_amd.h RPO_EPI_LN_*): the producer (BIAS_RESID) leaves the
+    act-dtype copy of its result and per-row 64-column partial statistics; the consumer takes that copy as A, the
+    gamma-scaled weight and s / b' and must reproduce  quickgelu(LN(x) W^T + b)  (clip/model.py:156-159 feeding
+    :174-175) to the tolerance of the unfolded path.  Every tile shape of the consumer gives the same bits."""
+    from rpo_amd import _lib as L
+    o = ops()
+    att, w_out, b_out = rnd((M, d), 1, 0.5), rnd((d, d), 2, d ** -0.5), rnd((d,), 3)
+    resid = rnd((M, d), 4, 2.0) + 0.4
+    w, b = rnd((N, d), 5, d ** -0.5), rnd((N,), 6)
+    gamma, beta = rnd((d,), 7, 0.1) + 1.0, rnd((d,), 8, 0.05)
+    dt = DT[mode]
+    xm = torch.full((M, d), float("nan"), device=dev())
+    xb = torch.full((M, d), float("nan"), dtype=dt, device=dev())
+    stats = torch.full((M, d // 64, 2), float("nan"), device=dev())
+    o.gemm_nt(att.to(dev(), dt), w_out.to(dev(), dt), xm, L.EPI_BIAS_RESID, bias=b_out.to(dev()), resid=resid.to(dev()),
+              out2=xb, ln_stats=stats)
+    xm64 = xm.double().cpu()
+    close(xm, q(att, mode) @ q(w_out, mode).t() + b_out.double() + resid.double(), "f32", "producer result", tol=1e-4)
+    assert torch.equal(xb.cpu(), xm.cpu().to(dt)), "out2 must be the RNE act-dtype copy of C"
+    grp = xm64.reshape(M, d // 64, 64)
+    ref_stats = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1)
+    close(stats, ref_stats, "f32", "partial row statistics", tol=2e-5)
+    # consumer: fold on the host exactly as Engine._fold does
+    wq = (w.double() * gamma.double()[None, :]).float().to(dt)
+    s = wq.double().sum(1).float()
+    bq = (b.double() + w.double() @ beta.double()).float()
+    mu = xm64.mean(1, keepdim=True)
+    rstd = (xm64.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    pre = ((xm64 - mu) * rstd * gamma.double() + beta.double()) @ w.double().t() + b.double()
+    row0 = M - 100
+    outs = {}
+    for cfg in (0, 8, 2, 5):
+        y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        aux = torch.full((M - row0, N), float("nan"), device=dev())
+        o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), aux=aux, aux_row0=row0,
+                  ln_stats=stats, ln_colsum=s.to(dev()), tile_config=cfg)
+        outs[cfg] = (y, aux)
+    close(outs[0][0], R.qgelu(pre), mode, "LN-folded c_fc", tol=1.5 * TOL[mode])
+    close(outs[0][1], pre[row0:], mode, "LN-folded saved u", tol=1.5 * TOL[mode])
+    for cfg in (8, 2, 5):
+        assert torch.equal(outs[cfg][0], outs[0][0]) and torch.equal(outs[cfg][1], outs[0][1]), f"tile_config {cfg}"
+    y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+    o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS, bias=bq.to(dev()), ln_stats=stats, ln_colsum=s.to(dev()))
+    close(y, pre, mode, "LN-folded in-proj", tol=1.5 * TOL[mode])
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_gemm_split_k_feeds_layernorm_bwd(mode):
     """split-K slabs (deterministic, no atomics) are summed by rpo_layernorm_bwd in slab order."""
