@@ -133,6 +133,13 @@ using CfgBig = Cfg<2, 4, 4, 2, 2, RPO_SPREAD_BIG>;
 #ifndef RPO_TALL_STAGES
 #define RPO_TALL_STAGES 2
 #endif
+// 128x128 owned by FOUR waves (64x64 each: 4 fragment reads feed 4 MFMAs per k-step).  The 8-wave layouts above read
+// 1.5 (128x128) / 2 (64x128) fragments per MFMA, i.e. 190 / 250 B/clk of LDS reads at full MFMA rate against the 256
+// the LDS delivers: the long-K, N = 768 GEMMs (c_proj, out-proj) were bound by that, not by HBM or the matrix pipe.
+#ifndef RPO_SPREAD_QUAD
+#define RPO_SPREAD_QUAD 4
+#endif
+using CfgQuad = Cfg<2, 2, 2, 2, 2, RPO_SPREAD_QUAD>;                  // 128x128, 4 waves
 using CfgTiny = Cfg<2, 2, 1, 1, RPO_TINY_STAGES, RPO_SPREAD_TINY>;    // 64x64, 4 waves
 using CfgTall = Cfg<2, 4, 1, 1, RPO_TALL_STAGES, RPO_SPREAD_TALL>;    // 64x128, 8 waves
 
@@ -773,6 +780,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 }
 
 #include "gemm_w4.inc"
+#include "gemm_w4g.inc"
 
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
@@ -821,6 +829,13 @@ int launch(const GemmParams& p, hipStream_t s) {
     constexpr bool epi_ln = EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU;
     const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK && (!epi_ln || p.K <= 16 * LN_GROUP);
     const bool wants_big = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills;
+    // 224x384 tiles when they cover the output in exactly one round and 256x256 tiles do not (c_fc at B = 32)
+    {
+      int rpt, tm_, tn_;
+      const bool g_ok = w4_ok && w4g_plan(p.M, p.N, &rpt, &tm_, &tn_);
+      const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
+      if (g_ok && (p.force_cfg == 10 || (big_shape && !fills))) return launch_w4g<TOut, EPI>(p, s);
+    }
     if (w4_ok && (p.force_cfg == 8 || wants_big)) return launch_w4<TOut, EPI>(p, s);
     if (ok && (p.force_cfg == 7 || wants_big)) return launch_pp<TOut, EPI>(p, s);
     if (ok && p.force_cfg == 3) return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
@@ -835,6 +850,9 @@ int launch(const GemmParams& p, hipStream_t s) {
 #ifndef RPO_TALL_N
 #define RPO_TALL_N 1024
 #endif
+  if constexpr (sizeof(TIn) == 2) {
+    if (p.force_cfg == 9) return launch_cfg<TIn, TOut, EPI, CfgQuad>(p, s);
+  }
   if (p.force_cfg == 6 || (p.force_cfg == 0 && p.N <= RPO_TALL_N)) return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
   return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
 }

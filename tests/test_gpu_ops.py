@@ -212,8 +212,44 @@ def test_gemm_one_wave_per_simd_256_bit_identical_and_race_screen(mode, M, N, K)
                 assert torch.equal(out, outs[8][0]), "one-wave-per-SIMD kernel is not deterministic: LDS race"
 
 
+@pytest.mark.parametrize("M,N,K", [(7072, 3072, 768), (7072, 3072, 128), (6000, 3072, 192), (7168, 2688, 256),
+                                   (7001, 3072, 3072)])
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-@pytest.mark.parametrize("M,d,N", [(300, 768, 3072), (4200, 768, 2304), (1000, 1024, 4096)])
+def test_gemm_one_round_224x384_bit_identical_and_race_screen(mode, M, N, K):
+    """The 224x384 one-wave-per-SIMD kernel (tile_config 10; generated k-loop, per-wave epilogue; what the heuristic
+    picks for c_fc at B = 32): against float64, bit-identical to the 128x128 kernel, rows-per-tile that do not divide
+    into 32 (221 of 224, 219, ...), M tails, K from two 64-deep tiles up, race screen of 25 launches."""
+    from rpo_amd import _lib as L
+    o = ops()
+    if mode == "f16" and K == 3072:
+        pytest.skip("one long-K case per format is enough (CPU reference matmul time)")
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias = rnd((N,), 3)
+    acc = q(a, mode) @ q(w, mode).t()
+    ad, wd, bd = a.to(dev(), DT[mode]), w.to(dev(), DT[mode]), bias.to(dev())
+    row0 = max(M - 800, 0)
+    for epi, ref in ((L.EPI_BIAS, acc + bias.double()), (L.EPI_BIAS_QGELU, R.qgelu(acc + bias.double()))):
+        outs = {}
+        for cfg in (10, 2):
+            out = torch.full((M, N), float("nan"), dtype=DT[mode], device=dev())
+            kw = dict(bias=bd)
+            if epi == L.EPI_BIAS_QGELU:
+                kw.update(aux_row0=row0, aux=torch.full((M - row0, N), float("nan"), device=dev()))
+            o.gemm_nt(ad, wd, out, epi, tile_config=cfg, **kw)
+            outs[cfg] = (out, kw.get("aux"))
+        close(outs[10][0], ref, mode, f"224x384 gemm epi {epi}")
+        assert torch.equal(outs[10][0], outs[2][0]), "128x128 tiles differ from the 224x384 kernel"
+        if epi == L.EPI_BIAS_QGELU:
+            assert torch.equal(outs[10][1], outs[2][1])
+        if epi == L.EPI_BIAS:
+            for _ in range(25):
+                out = torch.empty((M, N), dtype=DT[mode], device=dev())
+                o.gemm_nt(ad, wd, out, epi, tile_config=10, bias=bd)
+                assert torch.equal(out, outs[10][0]), "224x384 kernel is not deterministic: LDS race"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("M,d,N", [(300, 768, 3072), (4200, 768, 2304), (1000, 1024, 4096), (7072, 768, 3072)])
 def test_gemm_layernorm_fold(mode, M, d, N):
     """LayerNorm folded into the GEMM around it (include/rpo_amd.h RPO_EPI_LN_*): the producer (BIAS_RESID) leaves the
     act-dtype copy of its result and per-row 64-column partial statistics; the consumer takes that copy as A, the
@@ -246,7 +282,8 @@ def test_gemm_layernorm_fold(mode, M, d, N):
     pre = ((xm64 - mu) * rstd * gamma.double() + beta.double()) @ w.double().t() + b.double()
     row0 = M - 100
     outs = {}
-    for cfg in (0, 8, 2, 5):
+    cfgs = (0, 8, 2, 5) + ((10,) if (M, N) == (7072, 3072) else ())
+    for cfg in cfgs:
         y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
         aux = torch.full((M - row0, N), float("nan"), device=dev())
         o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), aux=aux, aux_row0=row0,
@@ -254,7 +291,7 @@ def test_gemm_layernorm_fold(mode, M, d, N):
         outs[cfg] = (y, aux)
     close(outs[0][0], R.qgelu(pre), mode, "LN-folded c_fc", tol=1.5 * TOL[mode])
     close(outs[0][1], pre[row0:], mode, "LN-folded saved u", tol=1.5 * TOL[mode])
-    for cfg in (8, 2, 5):
+    for cfg in cfgs[1:]:
         assert torch.equal(outs[cfg][0], outs[0][0]) and torch.equal(outs[cfg][1], outs[0][1]), f"tile_config {cfg}"
     y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
     o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS, bias=bq.to(dev()), ln_stats=stats, ln_colsum=s.to(dev()))

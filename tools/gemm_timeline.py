@@ -22,7 +22,8 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
                                      ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 3),
                                      ("qkv_pingpong (stamps per 32-deep k-tile)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 7),
                                      ("qkv_w4 (one wave per SIMD)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 8),
-                                     ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8)]:
+                                     ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8),
+                                     ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10)]:
     if os.environ.get("TIMELINE_ONLY") and os.environ["TIMELINE_ONLY"] not in name:
         continue
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
@@ -38,7 +39,7 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
         if r[0] == 0: continue
         nk = int((r[2:52] != 0).sum())
         deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
-        if cfg == 8:
+        if cfg in (8, 10):
             nk32 = K // 32
             print(f" wg {b*97:5d}: start->loop {int(r[2]-r[0]):6d} | loop {int(r[60]-r[2]):6d} = {nk32} tiles x {int(r[60]-r[2])//nk32} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}")
             continue
