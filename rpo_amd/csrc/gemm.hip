@@ -34,6 +34,8 @@
 // backward from running on a handful of CUs.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct GemmParams {
@@ -275,45 +277,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   else __builtin_amdgcn_s_barrier();         // everybody is done reading the last stage
   if constexpr (PRECONV) {
     const int nb = n0 + wn * (CF::WN_T * 32) + 4 * half;
-#pragma unroll
-    for (int tn = 0; tn < CF::WN_T; ++tn) {      // tn outermost: 4 bias quads live at a time (the one-wave-per-SIMD
-      float4 bias_r[4], sum_r[4];                // kernel arrives here with 256 accumulators)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bias_r[g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (IS_LN) sum_r[g] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nb + tn * 32 + 8 * g, p.N - 4));
-      }
-#pragma unroll
-      for (int tm = 0; tm < CF::WM_T; ++tm) {
-        float2 st = make_float2(0.f, 1.f);
-        if constexpr (IS_LN) st = row_stats[wm * (CF::WM_T * 32) + tm * 32 + l31];
-#pragma unroll
+    // The pre-activation store of the back-propagated rows exists only in the code path of tiles that hold such rows
+    // (uniform test): a per-quad `if` in the common path cuts it into 4-element basic blocks and leaves the
+    // mul -> exp -> add -> rcp -> mul chains of QuickGELU without independent work to hide their latency.
+    auto convert_and_stage = [&](auto save_u_tag) {
+      constexpr bool SAVE_U = decltype(save_u_tag)::value;
+  #pragma unroll
+      for (int tn = 0; tn < CF::WN_T; ++tn) {      // tn outermost: 4 bias quads live at a time (the one-wave-per-SIMD
+        float4 bias_r[4], sum_r[4];                // kernel arrives here with 256 accumulators)
+  #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
-          const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
-          const float4 b4 = bias_r[g];
-          float4 v;
-          if constexpr (IS_LN) {
-            const float4 s4 = sum_r[g];
-            v = make_float4(fmaf(st.y, acc[tn][tm][4 * g] - st.x * s4.x, b4.x), fmaf(st.y, acc[tn][tm][4 * g + 1] - st.x * s4.y, b4.y),
-                            fmaf(st.y, acc[tn][tm][4 * g + 2] - st.x * s4.z, b4.z), fmaf(st.y, acc[tn][tm][4 * g + 3] - st.x * s4.w, b4.w));
-          } else {
-            v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
-                            acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
+          bias_r[g] = HAS_BIAS ? *reinterpret_cast<const float4*>(p.bias + min(nb + tn * 32 + 8 * g, p.N - 4))
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (IS_LN) sum_r[g] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nb + tn * 32 + 8 * g, p.N - 4));
+        }
+  #pragma unroll
+        for (int tm = 0; tm < CF::WM_T; ++tm) {
+          float2 st = make_float2(0.f, 1.f);
+          if constexpr (IS_LN) st = row_stats[wm * (CF::WM_T * 32) + tm * 32 + l31];
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = wm * (CF::WM_T * 32) + tm * 32 + l31;
+            const int col = wn * (CF::WN_T * 32) + tn * 32 + 8 * g + 4 * half;
+            const float4 b4 = bias_r[g];
+            float4 v;
+            if constexpr (IS_LN) {
+              const float4 s4 = sum_r[g];
+              v = make_float4(fmaf(st.y, acc[tn][tm][4 * g] - st.x * s4.x, b4.x), fmaf(st.y, acc[tn][tm][4 * g + 1] - st.x * s4.y, b4.y),
+                              fmaf(st.y, acc[tn][tm][4 * g + 2] - st.x * s4.z, b4.z), fmaf(st.y, acc[tn][tm][4 * g + 3] - st.x * s4.w, b4.w));
+            } else {
+              v = make_float4(acc[tn][tm][4 * g] + b4.x, acc[tn][tm][4 * g + 1] + b4.y,
+                              acc[tn][tm][4 * g + 2] + b4.z, acc[tn][tm][4 * g + 3] + b4.w);
+            }
+            if (IS_QG) {
+              const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
+              if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
+                *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+              v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+            }
+            if constexpr (sizeof(TOut) == 2)
+              *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
+                  make_uint2(pack2<TOut>(v.x, v.y), pack2<TOut>(v.z, v.w));
           }
-          if (IS_QG) {
-            const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
-            if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
-              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
-            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-          }
-          if constexpr (sizeof(TOut) == 2)
-            *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
-                make_uint2(pack2<TOut>(v.x, v.y), pack2<TOut>(v.z, v.w));
         }
       }
-    }
+    };
+    if (IS_QG && p.aux != nullptr && m0 + BM > p.aux_row0) convert_and_stage(std::true_type{});
+    else convert_and_stage(std::false_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;                       // 16-B chunks per row
     constexpr int RPP = CF::THREADS / CPR;            // rows per pass
@@ -351,70 +361,75 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     else if (HAS_BIAS && nok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
     if (IS_LN && nok) s4 = *reinterpret_cast<const float4*>(p.ln_colsum + n);
     TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
-    for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
-      float4 ex[UNR];
-      int64_t orow[UNR];
-      bool ok[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int m = m0 + (pass0 + u) * RPP + r0;
-        ok[u] = nok && m < p.M;
-        const int mc = min(m, p.M - 1);
-        orow[u] = mc;
-        ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EpiPre<EPI, CF>::value) {            // loaded before the main loop (see the kernel)
-          ex[u] = pre[u];
-        } else if (EPI == RPO_EPI_PATCH) {
-          const int img = mc / p.group;
-          orow[u] = (int64_t)mc + img + 1;
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
-        } else if (EPI == RPO_EPI_BIAS_RESID) {
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
-        } else if (EPI == RPO_EPI_QGELU_BWD) {
-          if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
+    auto row_major_pass = [&](auto save_u_tag) {        // (see convert_and_stage above for the tag)
+      constexpr bool SAVE_U = decltype(save_u_tag)::value;
+      for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
+        float4 ex[UNR];
+        int64_t orow[UNR];
+        bool ok[UNR];
+  #pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int m = m0 + (pass0 + u) * RPP + r0;
+          ok[u] = nok && m < p.M;
+          const int mc = min(m, p.M - 1);
+          orow[u] = mc;
+          ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (EpiPre<EPI, CF>::value) {            // loaded before the main loop (see the kernel)
+            ex[u] = pre[u];
+          } else if (EPI == RPO_EPI_PATCH) {
+            const int img = mc / p.group;
+            orow[u] = (int64_t)mc + img + 1;
+            if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)(mc - img * p.group + 1) * p.ldr + n);
+          } else if (EPI == RPO_EPI_BIAS_RESID) {
+            if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
+          } else if (EPI == RPO_EPI_QGELU_BWD) {
+            if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
+          }
         }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int row = (pass0 + u) * RPP + r0;
-        const int m = m0 + row;
-        float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
-        if constexpr (IS_LN) {
-          const float2 st = row_stats[row];
-          v.x = fmaf(st.y, v.x - st.x * s4.x, b4.x); v.y = fmaf(st.y, v.y - st.x * s4.y, b4.y);
-          v.z = fmaf(st.y, v.z - st.x * s4.z, b4.z); v.w = fmaf(st.y, v.w - st.x * s4.w, b4.w);
-        } else {
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        }
-        if (IS_QG) {
-          if (ok[u] && p.aux != nullptr && m >= p.aux_row0)
-            *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
-          v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-        }
-        if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
-          v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
-        }
-        if (EPI == RPO_EPI_QGELU_BWD) {
-          v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
-          v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
-        }
-        if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
-        if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TAct) == 2) {
-          // LayerNorm fold, producer side: the 16-bit copy the consuming GEMM reads as its A operand, and the
-          // (mean, sum of squared deviations) of each 64-column group of the row: 16 consecutive lanes hold one group
-          if (p.out2 != nullptr && ok[u])
-            ActIO<TAct>::st4(reinterpret_cast<TAct*>(p.out2) + orow[u] * p.ldout2 + n, v.x, v.y, v.z, v.w);
-          if (p.ln_stats != nullptr) {
-            const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
-            const float mean = sm * (1.0f / LN_GROUP);
-            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-            const float q = row16_sum((dx * dx + dy * dy) + (dz * dz + dw * dw));
-            if (ok[u] && (cc & 15) == 0)
-              reinterpret_cast<float2*>(p.ln_stats)[orow[u] * (p.N / LN_GROUP) + (n >> 6)] = make_float2(mean, q);
+  #pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int row = (pass0 + u) * RPP + r0;
+          const int m = m0 + row;
+          float4 v = *reinterpret_cast<const float4*>(smem + row * CROW + cc * 16);
+          if constexpr (IS_LN) {
+            const float2 st = row_stats[row];
+            v.x = fmaf(st.y, v.x - st.x * s4.x, b4.x); v.y = fmaf(st.y, v.y - st.x * s4.y, b4.y);
+            v.z = fmaf(st.y, v.z - st.x * s4.z, b4.z); v.w = fmaf(st.y, v.w - st.x * s4.w, b4.w);
+          } else {
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          }
+          if (IS_QG) {
+            if (SAVE_U && ok[u] && m >= p.aux_row0)
+              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+          }
+          if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
+            v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
+          }
+          if (EPI == RPO_EPI_QGELU_BWD) {
+            v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
+            v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
+          }
+          if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
+          if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TAct) == 2) {
+            // LayerNorm fold, producer side: the 16-bit copy the consuming GEMM reads as its A operand, and the
+            // (mean, sum of squared deviations) of each 64-column group of the row: 16 consecutive lanes hold one group
+            if (p.out2 != nullptr && ok[u])
+              ActIO<TAct>::st4(reinterpret_cast<TAct*>(p.out2) + orow[u] * p.ldout2 + n, v.x, v.y, v.z, v.w);
+            if (p.ln_stats != nullptr) {
+              const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+              const float mean = sm * (1.0f / LN_GROUP);
+              const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+              const float q = row16_sum((dx * dx + dy * dy) + (dz * dz + dw * dw));
+              if (ok[u] && (cc & 15) == 0)
+                reinterpret_cast<float2*>(p.ln_stats)[orow[u] * (p.N / LN_GROUP) + (n >> 6)] = make_float2(mean, q);
+            }
           }
         }
       }
-    }
+    };
+    if (IS_QG && p.aux != nullptr && m0 + BM > p.aux_row0) row_major_pass(std::true_type{});
+    else row_major_pass(std::false_type{});
   }
 }
 

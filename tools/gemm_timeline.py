@@ -23,7 +23,8 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
                                      ("qkv_pingpong (stamps per 32-deep k-tile)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 7),
                                      ("qkv_w4 (one wave per SIMD)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 8),
                                      ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8),
-                                     ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10)]:
+                                     ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
+                                     ("c_fc_w4g bias-only epilogue (store cost alone)", 7072, 3072, 768, EPI_BIAS, torch.bfloat16, 10)]:
     if os.environ.get("TIMELINE_ONLY") and os.environ["TIMELINE_ONLY"] not in name:
         continue
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
