@@ -102,7 +102,11 @@ typedef struct rpo_gemm_args {
                                     LN_BIAS*: IN, the same array for the rows of A (groups = K / 64)  */
   const float* ln_colsum;        /* LN_BIAS*: s[n], fp32 [N]                                         */
   float ln_eps;                  /* LN_BIAS*: epsilon of the folded LayerNorm                        */
-  int32_t reserved0;
+  /* Optional tiling hint (results do not depend on it): the rows of A / C are two segments, [0, seg1_row0) and
+     [seg1_row0, M), and unit u owns rows [u * seg_rows0, +seg_rows0) of the first and [seg1_row0 + u * seg_rows1,
+     +seg_rows1) of the second -- the image tower's layout: N frozen rows + Kp prompt rows per image.  A kernel that
+     tiles one unit per workgroup then spreads the rows with extra epilogue work (saved pre-activations) evenly. */
+  int32_t seg_rows0, seg_rows1, seg1_row0;
 } rpo_gemm_args;
 
 int rpo_version(void);

@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
         ("ln_stats", c_vp),
         ("ln_colsum", c_vp),
         ("ln_eps", c_f32),
-        ("reserved0", c_i32),
+        ("seg_rows0", c_i32), ("seg_rows1", c_i32), ("seg1_row0", c_i32),
     ]
 
 

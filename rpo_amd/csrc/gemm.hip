@@ -55,6 +55,7 @@ struct GemmParams {
   float* ln_stats;
   const float* ln_colsum;
   float ln_eps;
+  int seg_rows0, seg_rows1, seg1_row0;      // tiling hint: see include/rpo_amd.h
 };
 
 constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic
@@ -846,8 +847,8 @@ int launch(const GemmParams& p, hipStream_t s) {
     const bool wants_big = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills;
     // 224x384 tiles when they cover the output in exactly one round and 256x256 tiles do not (c_fc at B = 32)
     {
-      int rpt, tm_, tn_;
-      const bool g_ok = w4_ok && w4g_plan(p.M, p.N, &rpt, &tm_, &tn_);
+      W4GPlan gplan;
+      const bool g_ok = w4_ok && w4g_plan(p, &gplan);
       const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
       if (g_ok && (p.force_cfg == 10 || (big_shape && !fills))) return launch_w4g<TOut, EPI>(p, s);
     }
@@ -954,6 +955,8 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.force_cfg = a->tile_config;
   p.out2 = static_cast<char*>(a->out2); p.ldout2 = a->ldout2;
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
+  p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
+  if (p.seg_rows0 < 0 || p.seg_rows1 < 0 || p.seg1_row0 < 0 || p.seg1_row0 > p.M) return RPO_E_BADARG;
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);

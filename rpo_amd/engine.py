@@ -315,6 +315,9 @@ class Engine:
                                       q_first=N)
                 lo = Rf
             timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
+            # tiling hint for c_fc: one image = N frozen + K prompt rows, so the rows whose pre-activations are saved
+            # are spread over all workgroups (rpo_gemm_args.seg_*)
+            units = (N, K, Rf) if lo == 0 else None
             # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
             prod = dict(out2=h[lo:], ln_stats=st[lo:]) if fold else {}
             with timed("out_proj"):
@@ -323,13 +326,13 @@ class Engine:
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                                 aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo,
-                                ln_stats=st[lo:], ln_colsum=blk.s_fc)
+                                ln_stats=st[lo:], ln_colsum=blk.s_fc, row_units=units)
             else:
                 with timed("ln_2"):
                     ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
-                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo)
+                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo, row_units=units)
             # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
             prod = dict(out2=h[lo:], ln_stats=st[lo:]) if (fold and l < last) else {}
             with timed("c_proj"):

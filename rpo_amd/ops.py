@@ -50,7 +50,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
             aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
             group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0,
             out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
-            ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS) -> torch.Tensor:
+            ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS,
+            row_units: Optional[tuple] = None) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
@@ -74,6 +75,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     split_stride=split_stride, tile_config=tile_config,
                     out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
+    if row_units is not None:               # (rows per unit in segment 0, rows per unit in segment 1, first row of segment 1)
+        args.seg_rows0, args.seg_rows1, args.seg1_row0 = row_units
     if ln_stats is not None:
         rows = a.shape[0] if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else M
         cols = K if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else N

@@ -249,6 +249,40 @@ def test_gemm_one_round_224x384_bit_identical_and_race_screen(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("n0,n1,units", [(197, 24, 32), (197, 4, 32), (197, 16, 32), (190, 34, 30), (224, 0, 28)])
+def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
+    """rpo_gemm_args.seg_rows0 / seg_rows1 / seg1_row0 (include/rpo_amd.h): the 224x384 kernel then builds one tile
+    from one unit's rows of BOTH row segments (an image's frozen rows + its prompt rows).  Output and saved
+    pre-activations must be the bits of the contiguous tiling and of the 128x128 kernel; a hint that does not describe
+    the matrix is ignored."""
+    from rpo_amd import _lib as L
+    o = ops()
+    K, N = 256, 3072
+    seg1 = n0 * units
+    M = seg1 + n1 * units
+    a, w, bias = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    ad, wd, bd = a.to(dev(), DT[mode]), w.to(dev(), DT[mode]), bias.to(dev())
+    row0 = seg1 if n1 else M - 300
+    res = {}
+    for name, cfg, hint in (("units", 10, (n0, n1, seg1)), ("contiguous", 10, None), ("128x128", 2, None),
+                            ("bad hint", 10, (n0 + 1, n1, seg1)), ("auto", 0, (n0, n1, seg1))):
+        out = torch.full((M, N), float("nan"), dtype=DT[mode], device=dev())
+        aux = torch.full((M - row0, N), float("nan"), device=dev())
+        o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0, tile_config=cfg, row_units=hint)
+        res[name] = (out, aux)
+    pre = q(a, mode) @ q(w, mode).t() + bias.double()
+    close(res["units"][0], R.qgelu(pre), mode, "row-unit tiles")
+    close(res["units"][1], pre[row0:], mode, "row-unit tiles, saved u")
+    for name in ("contiguous", "128x128", "bad hint", "auto"):
+        assert torch.equal(res[name][0], res["units"][0]) and torch.equal(res[name][1], res["units"][1]), name
+    for _ in range(10):
+        out = torch.empty((M, N), dtype=DT[mode], device=dev())
+        aux = torch.empty((M - row0, N), device=dev())
+        o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0, tile_config=10, row_units=(n0, n1, seg1))
+        assert torch.equal(out, res["units"][0]) and torch.equal(aux, res["units"][1]), "LDS race"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("M,d,N", [(300, 768, 3072), (4200, 768, 2304), (1000, 1024, 4096), (7072, 768, 3072)])
 def test_gemm_layernorm_fold(mode, M, d, N):
     """LayerNorm folded into the GEMM around it (include/rpo_amd.h RPO_EPI_LN_*): the producer (BIAS_RESID) leaves the
@@ -282,12 +316,14 @@ def test_gemm_layernorm_fold(mode, M, d, N):
     pre = ((xm64 - mu) * rstd * gamma.double() + beta.double()) @ w.double().t() + b.double()
     row0 = M - 100
     outs = {}
-    cfgs = (0, 8, 2, 5) + ((10,) if (M, N) == (7072, 3072) else ())
+    one_round = (M, N) == (7072, 3072)
+    cfgs = (0, 8, 2, 5) + ((10, "units") if one_round else ())
     for cfg in cfgs:
         y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
         aux = torch.full((M - row0, N), float("nan"), device=dev())
+        hint = dict(tile_config=10, row_units=(197, 24, 6304)) if cfg == "units" else dict(tile_config=cfg)
         o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), aux=aux, aux_row0=row0,
-                  ln_stats=stats, ln_colsum=s.to(dev()), tile_config=cfg)
+                  ln_stats=stats, ln_colsum=s.to(dev()), **hint)
         outs[cfg] = (y, aux)
     close(outs[0][0], R.qgelu(pre), mode, "LN-folded c_fc", tol=1.5 * TOL[mode])
     close(outs[0][1], pre[row0:], mode, "LN-folded saved u", tol=1.5 * TOL[mode])

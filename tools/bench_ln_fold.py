@@ -37,7 +37,7 @@ for name, N, K, epi_plain, epi_ln in (("in_proj", 2304, 768, EPI_BIAS, EPI_LN_BI
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     bias, s = torch.randn(N, device=dev), torch.randn(N, device=dev)
     out = torch.empty(M, N, dtype=dt, device=dev)
-    for cfg in (0, 8, 2):
+    for cfg in (0, 8, 2, 10):
         a = timeit(lambda: ops.gemm_nt(xb, w, out, epi_plain, bias=bias, tile_config=cfg))
         b = timeit(lambda: ops.gemm_nt(xb, w, out, epi_ln, bias=bias, ln_stats=stats, ln_colsum=s, tile_config=cfg))
         print(f"{name:8s} cfg{cfg}: plain {a:6.2f} us   LN-fold {b:6.2f} us   ({b - a:+.2f})")

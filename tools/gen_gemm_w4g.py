@@ -10,8 +10,8 @@ Geometry (see gemm_w4g.inc for the reasoning): tile 224 (M, 7 x 32) x 384 (N), f
 224 x 96 = 7 x 3 MFMA tiles (21 accumulators of 16 registers: operands %0..%15 are AGPR tuples, %16..%20 VGPR tuples).
 Fragment sets a / b: W fragments (3) then X fragments (7), 4 VGPRs each, v[176:215] / v[216:255].
 Scratch: v172 / v173 DMA offsets, v174 / v175 read addresses (W / X); s60 slot of the current tile, s61 DMA destination,
-s62 the other slot, s63 loop counter, s64 k byte offset of the tile being fetched, s65-s70 = i * 32 A rows (i = 1..6),
-s71-s81 = i * 32 W rows (i = 1..11).
+s62 the other slot, s63 loop counter, s64 k byte offset of the tile being fetched, s71-s81 = i * 32 W rows (i = 1..11);
+the A pieces take one offset operand each (%[offa0] .. %[offa6]): the rows of a tile may come from two row segments.
 """
 import os
 
@@ -40,10 +40,12 @@ def mfma(j, cur):
 
 
 def dma(kind, i):
-    off, srd = ("offa", "srda") if kind == "a" else ("offw", "srdw")
     lds = 4096 * i + (0 if kind == "a" else A_BYTES)
+    if kind == "a":                                  # per-piece offsets: the rows of a tile need not be contiguous
+        return f'"s_add_u32 m0, s61, {lds}\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %[offa{i}], %[srda], s64 offen lds\\n\\t"'
+    off, srd = "offw", "srdw"
     tmp = "v172" if i % 2 else "v173"
-    srow = f"s{64 + i}" if kind == "a" else f"s{70 + i}"
+    srow = f"s{70 + i}"
     pre = f"v_add_u32 {tmp}, {srow}, %[{off}]\\n\\t" if i > 0 else ""
     vo = tmp if i > 0 else f"%[{off}]"
     return f'"{pre}s_add_u32 m0, s61, {lds}\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 {vo}, %[{srd}], s64 offen lds\\n\\t"'
@@ -115,7 +117,6 @@ def tile(p0, p1, p3, read_next=True):
 
 def main():
     L = ['"s_mov_b32 s60, 0\\n\\ts_mov_b32 s64, 0\\n\\ts_mov_b32 s63, %[nloop]\\n\\t"']
-    L += ['"s_mov_b32 s65, %[rsa]\\n\\t"'] + [f'"s_add_u32 s{65 + i}, s{64 + i}, %[rsa]\\n\\t"' for i in range(1, 6)]
     L += ['"s_mov_b32 s71, %[rsw]\\n\\t"'] + [f'"s_add_u32 s{71 + i}, s{70 + i}, %[rsw]\\n\\t"' for i in range(1, 11)]
     # prologue: tile 0 into slot 0, the A pieces of tile 1 into slot 1; tile 0 retired, published, its first reads issued
     L += ['"s_mov_b32 s61, %[ldsw]\\n\\t"'] + [dma("a", i) for i in range(NA)] + [dma("w", i) for i in range(NW)]
