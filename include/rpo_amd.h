@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 2
+#define RPO_ABI_VERSION 3
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -193,8 +193,11 @@ int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, const void* vc
  *   logits[b,c] = (scale_exp / K) * sum_i <img_f[b,i]/|.|, text_f[c,i]/|.|>
  *   loss = mean_b CE(logits[b], label[b])
  * img_f [B,K,e], text_f [C,K,e], logits [B,C], loss [1], d_img_f / d_text_f like the inputs, all fp32.
- * label: int64 device array [B], or NULL for eval (only logits are written).
- * workspace: fp32, at least rpo_head_workspace_floats(B, C, K, e) elements. */
+ * label: int64 device array [B], or NULL for eval (only logits are written).  A target outside [0, C) makes the loss
+ * NaN (F.cross_entropy raises; a kernel cannot) and reads nothing out of bounds.
+ * workspace: fp32, at least rpo_head_workspace_floats(B, C, K, e) elements; no initialisation needed.
+ * Two launches per training step for class sets up to 128 (logits + norms over B*C blocks; backward with the softmax
+ * recomputed per block), three above; e <= 1024. */
 int64_t rpo_head_workspace_floats(int B, int C, int K, int e);
 int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
                      float* logits, float* loss, float* d_img_f, float* d_text_f,

@@ -101,46 +101,58 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// unit vectors and inverse norms of every feature row (trainers/rpo.py:215-219); image rows then class rows, one launch
-__global__ __launch_bounds__(256) void head_normalize_kernel(const float* __restrict__ f_img, float* u_img, float* n_img,
-                                                             int rows_img, const float* __restrict__ f_txt, float* u_txt,
-                                                             float* n_txt, int e) {
+// logits[b,c] = (scale/K) * sum_i <x_i, t_i> / (|x_i| |t_i|)   (trainers/rpo.py:215-227), x_i = img_f[b,i], t_i = text_f[c,i].
+// One block per (class, image): B * C independent blocks (608 for the Oxford-Pets base split at B = 32), wave w takes the
+// pairs i = w, w+4, ...; a pair is one pass over both raw rows accumulating <x,t>, |x|^2 and |t|^2 -- no separate
+// normalisation launch, no unit-vector copies.  The inverse norms the backward needs are left in ni / nt by the blocks of
+// class 0 / image 0.  (A version with one block per image that looped over all C * K text rows took 150 us: 120 dependent
+// load -> reduce rounds per wave on 32 CUs.)
+template <bool VEC>
+__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ f_img, const float* __restrict__ f_txt,
+                                                          float* ni, float* nt, float* logits, int C, int K, int e,
+                                                          float mul) {
   __shared__ float red[4];
-  const bool img = (int)blockIdx.x < rows_img;
-  const int r = img ? blockIdx.x : blockIdx.x - rows_img;
-  const float* x = (img ? f_img : f_txt) + (int64_t)r * e;
-  float* unit = img ? u_img : u_txt;
-  float* inv_norm = img ? n_img : n_txt;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < e; i += 256) s += x[i] * x[i];
-  const float inv = 1.0f / sqrtf(block_sum(s, red));
-  for (int i = threadIdx.x; i < e; i += 256) unit[(int64_t)r * e + i] = x[i] * inv;
-  if (threadIdx.x == 0) inv_norm[r] = inv;
-}
-
-// logits[b,c] = (scale/K) * sum_{i,e} ih[b,i,e] th[c,i,e]   (trainers/rpo.py:221-227)
-// one block = one image x 4 classes: the image row is read once per block instead of once per class
-constexpr int HEAD_CPB = 4;
-__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ ih,
-                                                          const float* __restrict__ th, float* logits, int C,
-                                                          int Ke, float mul) {
-  __shared__ float red[4];
-  const int c0 = blockIdx.x * HEAD_CPB, b = blockIdx.y;
-  const float* x = ih + (int64_t)b * Ke;
-  const float* y[HEAD_CPB];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+#pragma unroll 2
+  for (int i = wave; i < K; i += 4) {
+    const float* x = f_img + ((int64_t)b * K + i) * e;
+    const float* t = f_txt + ((int64_t)c * K + i) * e;
+    float dot = 0.f, sx = 0.f, st = 0.f;
+    if constexpr (VEC) {                                           // e % 256 == 0, e <= 1024: all loads in flight at once
+      float4 xv[4], tv[4];
+      const int nv = e >> 8;
 #pragma unroll
-  for (int j = 0; j < HEAD_CPB; ++j) y[j] = th + (int64_t)min(c0 + j, C - 1) * Ke;
-  float s[HEAD_CPB] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < Ke; i += 256) {
-    const float xv = x[i];
+      for (int j = 0; j < 4; ++j)
+        if (j < nv) {
+          xv[j] = *reinterpret_cast<const float4*>(x + j * 256 + lane * 4);
+          tv[j] = *reinterpret_cast<const float4*>(t + j * 256 + lane * 4);
+        }
 #pragma unroll
-    for (int j = 0; j < HEAD_CPB; ++j) s[j] = fmaf(xv, y[j][i], s[j]);
+      for (int j = 0; j < 4; ++j)
+        if (j < nv) {
+          dot += xv[j].x * tv[j].x + xv[j].y * tv[j].y + xv[j].z * tv[j].z + xv[j].w * tv[j].w;
+          sx += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
+          st += tv[j].x * tv[j].x + tv[j].y * tv[j].y + tv[j].z * tv[j].z + tv[j].w * tv[j].w;
+        }
+    } else {
+      for (int idx = lane; idx < e; idx += 64) {
+        const float xv = x[idx], tv = t[idx];
+        dot = fmaf(xv, tv, dot); sx = fmaf(xv, xv, sx); st = fmaf(tv, tv, st);
+      }
+    }
+    dot = wave_sum(dot); sx = wave_sum(sx); st = wave_sum(st);
+    const float ix = 1.0f / sqrtf(sx), it = 1.0f / sqrtf(st);
+    acc += dot * ix * it;
+    if (lane == 0) {
+      if (c == 0) ni[(int64_t)b * K + i] = ix;
+      if (b == 0) nt[(int64_t)c * K + i] = it;
+    }
   }
-#pragma unroll
-  for (int j = 0; j < HEAD_CPB; ++j) {
-    const float t = block_sum(s[j], red);
-    if (threadIdx.x == 0 && c0 + j < C) logits[(int64_t)b * C + c0 + j] = t * mul;
-  }
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) logits[(int64_t)b * C + c] = ((red[0] + red[1]) + (red[2] + red[3])) * mul;
 }
 
 // per image: loss_b = logsumexp - logit[label]; dl[b,c] = (softmax - onehot) * gmul
@@ -167,134 +179,99 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) loss_b[b] = lb_ok ? (m + logf(s)) - z[lb] : __builtin_nanf("");
 }
 
-// Forward side of the head in ONE launch for class sets that fit a block (C <= 128; the Oxford-Pets base split has 19):
-// block b = image b.  Phase 1: its K image rows are normalised (unit rows -> LDS and ws for the backward).  Phase 2:
-// wave w owns classes w, w+4, ...; per (class, pair) one pass over e computes <img_unit, text> and |text|^2 with
-// wave shuffles only; block 0 also leaves the unit text rows / inverse norms for the backward.  Phase 3: wave 0 turns
-// the C logits of the image into its CE loss and dl row.  (The mean over the batch is taken by block 0 of
-// head_bwd_kernel: the kernel boundary is the only cross-block ordering needed.)
-__global__ __launch_bounds__(256) void head_fwd_fused_kernel(const float* __restrict__ f_img, const float* __restrict__ f_txt,
-                                                             const int64_t* __restrict__ label, float* ih, float* ni,
-                                                             float* th, float* nt, float* logits, float* dl, float* loss_b,
-                                                             int C, int K, int e, float mul, float gmul) {
-  extern __shared__ __attribute__((aligned(16))) char head_smem[];
-  float* img_u = reinterpret_cast<float*>(head_smem);            // [K][e] unit rows of this image
-  float* lg = img_u + (int64_t)K * e;                            // [C]
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = e / 256;                                        // float4 per lane per row (e % 256 == 0)
-  for (int i = wave; i < K; i += 4) {
-    const float* x = f_img + ((int64_t)b * K + i) * e;
-    float4 v[4];
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nv) {
-        v[j] = *reinterpret_cast<const float4*>(x + j * 256 + lane * 4);
-        ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-      }
-    const float inv = 1.0f / sqrtf(wave_sum(ss));
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nv) {
-        const float4 u = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
-        *reinterpret_cast<float4*>(img_u + i * e + j * 256 + lane * 4) = u;
-        *reinterpret_cast<float4*>(ih + ((int64_t)b * K + i) * e + j * 256 + lane * 4) = u;
-      }
-    if (lane == 0) ni[(int64_t)b * K + i] = inv;
-  }
-  __syncthreads();
-  for (int c = wave; c < C; c += 4) {
-    float acc = 0.f;
-    for (int i = 0; i < K; ++i) {
-      const float* t = f_txt + ((int64_t)c * K + i) * e;
-      float4 v[4];
-      float dot = 0.f, ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nv) {
-          v[j] = *reinterpret_cast<const float4*>(t + j * 256 + lane * 4);
-          const float4 u = *reinterpret_cast<const float4*>(img_u + i * e + j * 256 + lane * 4);
-          dot += v[j].x * u.x + v[j].y * u.y + v[j].z * u.z + v[j].w * u.w;
-          ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-        }
-      dot = wave_sum(dot);
-      const float inv = 1.0f / sqrtf(wave_sum(ss));
-      acc += dot * inv;
-      if (b == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < nv)
-            *reinterpret_cast<float4*>(th + ((int64_t)c * K + i) * e + j * 256 + lane * 4) =
-                make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
-        if (lane == 0) nt[(int64_t)c * K + i] = inv;
-      }
-    }
-    if (lane == 0) { lg[c] = acc * mul; logits[(int64_t)b * C + c] = acc * mul; }
-  }
-  if (label == nullptr) return;
-  __syncthreads();
-  if (wave == 0) {                                               // C <= 128: two logits per lane
-    const float z0 = lane < C ? lg[lane] : -INFINITY, z1 = lane + 64 < C ? lg[lane + 64] : -INFINITY;
-    const float m = wave_max(fmaxf(z0, z1));
-    const float e0 = lane < C ? expf(z0 - m) : 0.f, e1 = lane + 64 < C ? expf(z1 - m) : 0.f;
-    const float ssum = wave_sum(e0 + e1);
-    const int64_t lb64 = label[b];                               // out of range: NaN loss, no out-of-bounds access
-    const bool lb_ok = lb64 >= 0 && lb64 < C;
-    const int lb = lb_ok ? (int)lb64 : -1;
-    const float inv = 1.0f / ssum;
-    if (lane < C) dl[(int64_t)b * C + lane] = (e0 * inv - (lane == lb ? 1.0f : 0.0f)) * gmul;
-    if (lane + 64 < C) dl[(int64_t)b * C + lane + 64] = (e1 * inv - (lane + 64 == lb ? 1.0f : 0.0f)) * gmul;
-    if (lane == 0) loss_b[b] = lb_ok ? (m + logf(ssum)) - lg[lb] : __builtin_nanf("");
-  }
-}
-
 // one block per feature row (g, i) of the "self" side; other side has `n_other` groups.
-//   dh[e] = sum_o dl(g,o) * other_unit[o, i, e];  df = (dh - h * <h,dh>) * inv_norm
+//   h = f / |f|;  dh[e] = sum_o dl(g,o) * other[o,i,e] / |other[o,i]|;  df = (dh - h * <h,dh>) / |f|
 // Blocks [0, B*K) are the image rows (dl[g*C + o], o = class), blocks [B*K, B*K + C*K) the class rows
-// (dl[o*C + g], o = image): both sides in ONE launch.
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ ih,
-                                                       const float* __restrict__ ni, const float* __restrict__ th,
+// (dl[o*C + g], o = image): both sides in ONE launch, from the raw features and the inverse norms of head_logits_kernel.
+// FUSED_CE (class sets up to 128): there is no cross-entropy launch and no dl array -- every block recomputes the
+// softmax statistics (max, 1 / sum) it needs from the logits (its own image's row, or all B rows for a class-row block:
+// B * C <= a few thousand exps) and forms its dl weights in LDS; block 0 also writes the mean loss.  Fixed summation
+// orders throughout.  F.cross_entropy (trainers/rpo.py:230) raises on an out-of-range target; a kernel cannot, so it
+// neither reads out of bounds nor returns a plausible number: the loss becomes NaN (hosts validate labels they can see).
+template <bool FUSED_CE>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ f_img,
+                                                       const float* __restrict__ ni, const float* __restrict__ f_txt,
                                                        const float* __restrict__ nt, float* d_img_f, float* d_text_f,
-                                                       int B, int C, int K, int e, const float* loss_b, float* loss) {
+                                                       int B, int C, int K, int e, const float* loss_b, float* loss,
+                                                       const float* __restrict__ logits,
+                                                       const int64_t* __restrict__ label, float gmul) {
+  extern __shared__ __attribute__((aligned(16))) char head_smem[];
   __shared__ float red[4];
-  if (loss != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    // mean CE over the batch, fixed summation order
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += loss_b[b];
-    *loss = s / (float)B;
-  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool img = (int)blockIdx.x < B * K;
   const int row = img ? blockIdx.x : blockIdx.x - B * K;            // g*K + i
   const int g = row / K, i = row % K;
-  const float* self_unit = img ? ih : th;
+  const float* self_raw = img ? f_img : f_txt;
   const float* self_inv = img ? ni : nt;
-  const float* other_unit = img ? th : ih;
+  const float* other_raw = img ? f_txt : f_img;
+  const float* other_inv = img ? nt : ni;
   float* df = img ? d_img_f : d_text_f;
   const int n_other = img ? C : B;
-  const int64_t sg = img ? C : 1, so = img ? 1 : C;
-  const float* h = self_unit + (int64_t)row * e;
-  float dot = 0.f;
-  // e <= 4 * 256 handled in registers
-  float dh[4] = {0.f, 0.f, 0.f, 0.f};
+  float* wts = reinterpret_cast<float*>(head_smem);               // [max(B, C)]  dl(g, o) / |other[o, i]|
+  if constexpr (FUSED_CE) {
+    float* smax = wts + max(B, C);                                  // [B]
+    float* sinv = smax + B;                                         // [B]
+    float* lrow = sinv + B;                                         // [B] per-image loss (block 0)
+    const bool all = !img || blockIdx.x == 0;                       // statistics of every image, or of image g only
+    for (int b = all ? wave : g + wave; b < (all ? B : g + 1); b += 4) {
+      const float z0 = lane < C ? logits[(int64_t)b * C + lane] : -INFINITY;
+      const float z1 = lane + 64 < C ? logits[(int64_t)b * C + lane + 64] : -INFINITY;
+      const float m = wave_max(fmaxf(z0, z1));
+      const float ssum = wave_sum((lane < C ? expf(z0 - m) : 0.f) + (lane + 64 < C ? expf(z1 - m) : 0.f));
+      if (lane == 0) {
+        smax[b] = m; sinv[b] = 1.0f / ssum;
+        if (blockIdx.x == 0) {
+          const int64_t lb = label[b];
+          lrow[b] = lb >= 0 && lb < C ? (m + logf(ssum)) - logits[(int64_t)b * C + lb] : __builtin_nanf("");
+        }
+      }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                      // mean CE over the batch
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += lrow[b];
+      *loss = s / (float)B;
+    }
+    for (int o = threadIdx.x; o < n_other; o += 256) {
+      const int b = img ? g : o, c = img ? o : g;
+      const float p = expf(logits[(int64_t)b * C + c] - smax[b]) * sinv[b];
+      wts[o] = (p - (label[b] == (int64_t)c ? 1.0f : 0.0f)) * gmul * other_inv[(int64_t)o * K + i];
+    }
+  } else {
+    if (loss != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // mean CE over the batch, fixed summation order
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += loss_b[b];
+      *loss = s / (float)B;
+    }
+    const int64_t sg = img ? C : 1, so = img ? 1 : C;
+    for (int o = threadIdx.x; o < n_other; o += 256) wts[o] = dl[g * sg + o * so] * other_inv[(int64_t)o * K + i];
+  }
+  __syncthreads();
+  const float inv = self_inv[row];
+  float h[4], dh[4] = {0.f, 0.f, 0.f, 0.f};                         // e <= 4 * 256 handled in registers
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = threadIdx.x + 256 * v;
+    h[v] = idx < e ? self_raw[(int64_t)row * e + idx] * inv : 0.f;
+  }
+#pragma unroll 4
   for (int o = 0; o < n_other; ++o) {
-    const float w = dl[g * sg + o * so];
-    const float* y = other_unit + ((int64_t)o * K + i) * e;
+    const float w = wts[o];
+    const float* y = other_raw + ((int64_t)o * K + i) * e;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int idx = threadIdx.x + 256 * v;
       if (idx < e) dh[v] = fmaf(w, y[idx], dh[v]);
     }
   }
+  float dot = 0.f;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int idx = threadIdx.x + 256 * v;
-    if (idx < e) dot = fmaf(h[idx], dh[v], dot);
-  }
+  for (int v = 0; v < 4; ++v) dot = fmaf(h[v], dh[v], dot);
   dot = block_sum(dot, red);
-  const float inv = self_inv[row];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int idx = threadIdx.x + 256 * v;
-    if (idx < e) df[(int64_t)row * e + idx] = (dh[v] - h[idx] * dot) * inv;
+    if (idx < e) df[(int64_t)row * e + idx] = (dh[v] - h[v] * dot) * inv;
   }
 }
 
@@ -439,32 +416,30 @@ extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const i
   if (label && (!loss || !d_img_f || !d_text_f)) return RPO_E_BADARG;
   if (e > 1024) return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float* ih = ws;
-  float* th = ih + (int64_t)B * K * e;
-  float* ni = th + (int64_t)C * K * e;
+  float* ni = ws;
   float* nt = ni + (int64_t)B * K;
   float* dl = nt + (int64_t)C * K;
   float* lb = dl + (int64_t)B * C;
   const float gmul = scale_exp / ((float)K * (float)B);
-  // Small class sets (the few-shot base / new splits): the whole forward side in one launch, two launches per
-  // training step.  Larger ones (ImageNet: 500 / 1000 classes) spread the logits over (class group, image) blocks.
-  const size_t fused_lds = ((size_t)K * e + C) * sizeof(float);
-  if (C <= 128 && e % 256 == 0 && fused_lds <= 64 * 1024) {
-    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(B), dim3(256), fused_lds, s, img_f, text_f, label, ih, ni, th, nt,
-                       logits, dl, lb, C, K, e, scale_exp / (float)K, gmul);
-    if (label)
-      hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K + C * K), dim3(256), 0, s, dl, ih, ni, th, nt, d_img_f, d_text_f,
-                         B, C, K, e, lb, loss);
+  const float mul = scale_exp / (float)K;
+  if (e % 256 == 0 && aligned16(img_f) && aligned16(text_f))
+    hipLaunchKernelGGL(head_logits_kernel<true>, dim3(C, B), dim3(256), 0, s, img_f, text_f, ni, nt, logits, C, K, e, mul);
+  else
+    hipLaunchKernelGGL(head_logits_kernel<false>, dim3(C, B), dim3(256), 0, s, img_f, text_f, ni, nt, logits, C, K, e, mul);
+  if (!label) return rpo_launch_status();
+  // Small class sets (the few-shot base / new splits; 19 for Oxford-Pets base): two launches per training step, the
+  // cross-entropy is recomputed inside the backward blocks.  Larger ones (ImageNet: 500 / 1000 classes) get their own
+  // cross-entropy launch and a dl array.
+  const int nmax = B > C ? B : C;
+  if (C <= 128 && B <= 2048) {
+    hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(B * K + C * K), dim3(256), (size_t)(nmax + 3 * B) * sizeof(float), s,
+                       dl, img_f, ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul);
     return rpo_launch_status();
   }
-  hipLaunchKernelGGL(head_normalize_kernel, dim3(B * K + C * K), dim3(256), 0, s, img_f, ih, ni, B * K, text_f, th, nt, e);
-  hipLaunchKernelGGL(head_logits_kernel, dim3((C + HEAD_CPB - 1) / HEAD_CPB, B), dim3(256), 0, s, ih, th, logits, C, K * e,
-                     scale_exp / (float)K);
-  if (label) {
-    hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(B * K + C * K), dim3(256), 0, s, dl, ih, ni, th, nt, d_img_f, d_text_f,
-                       B, C, K, e, lb, loss);
-  }
+  if ((size_t)nmax * sizeof(float) > 64 * 1024) return RPO_E_SHAPE;
+  hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
+  hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(B * K + C * K), dim3(256), (size_t)nmax * sizeof(float), s, dl, img_f,
+                     ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul);
   return rpo_launch_status();
 }
 

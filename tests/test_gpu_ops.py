@@ -490,7 +490,8 @@ def test_text_attn_fwd_bwd(mode):
         close(outc[sl], ref, mode, f"text causal attn class {c}", tol=None if mode == "f32" else 8e-3)
 
 
-@pytest.mark.parametrize("B,C,K,e", [(4, 19, 24, 512), (3, 300, 4, 768), (1, 2, 1, 64)])
+@pytest.mark.parametrize("B,C,K,e", [(4, 19, 24, 512), (32, 19, 24, 512), (100, 37, 16, 512), (5, 128, 8, 768),
+                                     (3, 300, 4, 768), (1, 2, 1, 64), (7, 3, 5, 100)])
 def test_head_fwd_bwd(B, C, K, e):
     o = ops()
     i_f, t_f = rnd((B, K, e), 31), rnd((C, K, e), 32)
@@ -508,6 +509,11 @@ def test_head_fwd_bwd(B, C, K, e):
     logits.zero_()
     o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), None, 100.0, logits, None, None, None, ws)
     close(logits, lg, "f32", "head logits (eval)", tol=5e-6)
+    # an out-of-range target: F.cross_entropy raises; the kernel reports NaN and touches nothing out of bounds
+    bad = lab.clone(); bad[B // 2] = C
+    o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), bad.to(dev()), 100.0, logits, loss, d_i, d_t, ws)
+    assert torch.isnan(loss).item()
+    close(logits, lg, "f32", "head logits (bad label)", tol=5e-6)
 
 
 def test_sgd_broadcast_reduce_convert():

@@ -25,8 +25,12 @@ for k in 4 8 16 24 48; do timeout 200 python bench.py --K $k --steps 30 --warmup
 : > $O/bench_batchsweep.json
 for b in 4 8 16 64 128; do timeout 200 python bench.py --batch $b --steps 40 --warmup 5 $B >> $O/bench_batchsweep.json 2>> $O/bench.err; done
 timeout 200 python bench.py --dtype f32 --steps 20 --warmup 5 $B > $O/bench_f32.json 2>> $O/bench.err
+timeout 200 python bench.py --dtype f16 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_f16.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench_eval.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
+timeout 100 python tools/probe_per_layer.py > $O/per_layer_probe.txt 2>&1
+BENCH_CFGS=2,3,7,8,10 timeout 200 python tools/bench_gemm.py > $O/bench_gemm.txt 2>&1
+[ -x tools/build/ubench_dma ] && timeout 100 tools/build/ubench_dma > $O/ubench_dma.txt 2>&1
 ls $O

@@ -17,10 +17,10 @@ if db:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n"
                 "# NB: kernel tracing serialises the two HIP queues; per-kernel durations are valid, overlap is not.\n")
         f.write(txt + "\n# last step:\n" + tl)
-SH = {"qkv": "in-proj 7072x2304x768 bias (256x256 ping-pong kernel), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
-      "out_proj": "out-proj 7072x768x768 bias+residual (64x128 tiles), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
-      "c_fc": "c_fc 7072x3072x768 bias+QuickGELU (128x128 tiles), 33.4 GFLOP, 10.9+4.7+43.4 MB",
-      "c_proj": "c_proj 7072x768x3072 bias+residual (64x128 tiles), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
+SH = {"qkv": "in-proj 7072x2304x768 bias (gemm_w4_kernel: 256x256 tiles, one wave per SIMD, asm k-loop), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
+      "out_proj": "out-proj 7072x768x768 bias+residual (gemm_nt_kernel, 64x128 tiles), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
+      "c_fc": "c_fc 7072x3072x768 bias+QuickGELU (gemm_w4g_kernel: 224x384 tiles, one round of 256 workgroups), 33.4 GFLOP, 10.9+4.7+43.4 MB",
+      "c_proj": "c_proj 7072x768x3072 bias+residual (gemm_nt_kernel, 64x128 tiles), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
 lines = ["# PMC counters per launch (mean over launches) of the four forward GEMMs of one image-tower block at B=32,\n"
          "# from separate `rocprofv3 --kernel-trace --pmc <set>` passes over `tools/bench_gemm.py --only <shape>`.\n"
          "# FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x.\n"
@@ -36,7 +36,7 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if "gemm_nt_kernel" in r["Kernel_Name"] or "gemm_pp_kernel" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("gemm_nt_kernel", "gemm_pp_kernel", "gemm_w4_kernel", "gemm_w4g_kernel")):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, x in agg.items():
             vals[k] = sum(x) / len(x)
@@ -97,7 +97,7 @@ if f:
             fo.write("# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python bench.py --steps 6 --warmup 2\n"
                      "# SQ_VALU_MFMA_BUSY_CYCLES summed over the kernels of ONE train step (SIMD-cycles, 1024 SIMDs).  Per-dispatch\n"
                      "# GRBM_GUI_ACTIVE is inflated by the profiler for small kernels, so the step-level utilisation is taken against the\n"
-                     "# UN-profiled step time of r01_bench.json instead.\n")
+                     "# UN-profiled step time of the same refresh's bench.json instead.\n")
             fo.write(f"SQ_VALU_MFMA_BUSY_CYCLES_per_step {busy:.6g}\n")
             fo.write(f"all_simd_busy_cycles_per_step {busy / 1024:.6g}\n")
             fo.write("# cross-check: 1333.8 executed GFLOP / (1024 SIMDs * 1024 flop/cycle) = 1.272e6 cycles of pure MFMA work\n")
@@ -109,11 +109,12 @@ if f:
                 ga = v.get("GRBM_GUI_ACTIVE", 0.0)
                 if ga > 0 and busy > 0:
                     fo.write(f"{nm:72s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / busy:6.3f} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (ga / 8 * 1024):6.3f}\n")
-for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_eval.json", "bench_input_pipeline.json", "bench_batchsweep.json"):
+for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_f16.json", "bench_eval.json", "bench_input_pipeline.json",
+           "bench_batchsweep.json", "bench_2rank_selflaunch.json"):
     src = os.path.join(raw, fn)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
-for fn in ("gemm_timeline.txt", "graph_phases.txt"):
+for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
