@@ -107,6 +107,11 @@ typedef struct rpo_gemm_args {
      +seg_rows1) of the second -- the image tower's layout: N frozen rows + Kp prompt rows per image.  A kernel that
      tiles one unit per workgroup then spreads the rows with extra epilogue work (saved pre-activations) evenly. */
   int32_t seg_rows0, seg_rows1, seg1_row0;
+  /* Columns per partial row statistic in ln_stats: 0 or 64 (default), or 96.  96 is what the one-round 224x96 kernel
+     writes (BIAS_RESID with a row-unit hint, N % 96 == 0, K % 256 == 0: tile_config 11 / the heuristic's choice for the
+     image tower's out-proj and c_proj); a producer that cannot write the requested layout returns RPO_E_SHAPE, and the
+     consuming LN_BIAS* GEMM must be given the same value. */
+  int32_t ln_group;
 } rpo_gemm_args;
 
 int rpo_version(void);
@@ -117,6 +122,12 @@ const char* rpo_error_string(int code);
  * nn.MultiheadAttention's packed in-proj and out-proj (clip/model.py:171-177,186) and,
  * in the backward, autograd's mm(dY, W) (trainers/rpo.py:308). */
 int rpo_gemm_nt(const rpo_gemm_args* args, void* stream);
+
+/* The partial-statistics layout (rpo_gemm_args.ln_group: 64 or 96) a BIAS_RESID producer writes for these shapes,
+ * dtypes and row units when the kernel choice is left to the library (tile_config 0).  Only M, N, K, lda, ldw, the
+ * dtypes, split_k and seg_* are looked at.  Callers size ln_stats as [M, N / group, 2] floats and pass the same group to
+ * the producer and to the LN_BIAS* consumer. */
+int rpo_gemm_stats_group(const rpo_gemm_args* args);
 
 /* y = LayerNorm(x) * gamma + beta, statistics in fp32, eps as given (1e-5).
  * x fp32 [rows, d] (ldx), y in y_dtype.  d % 4 == 0, d <= 2048.  In-place (y == x, fp32) is allowed.

@@ -48,12 +48,14 @@ class GemmArgs(C.Structure):
         ("ln_colsum", c_vp),
         ("ln_eps", c_f32),
         ("seg_rows0", c_i32), ("seg_rows1", c_i32), ("seg1_row0", c_i32),
+        ("ln_group", c_i32),
     ]
 
 
 # name -> (restype, argtypes); must list every symbol include/rpo_amd.h declares
 SIGNATURES = {
     "rpo_version": (c_i32, []),
+    "rpo_gemm_stats_group": (c_i32, [C.POINTER(GemmArgs)]),
     "rpo_error_string": (C.c_char_p, [c_i32]),
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),

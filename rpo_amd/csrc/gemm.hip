@@ -56,9 +56,10 @@ struct GemmParams {
   const float* ln_colsum;
   float ln_eps;
   int seg_rows0, seg_rows1, seg1_row0;      // tiling hint: see include/rpo_amd.h
+  int ln_group;                             // columns per partial LayerNorm statistic (64, or 96: gemm_w4k.inc)
 };
 
-constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic
+constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic written by the generic epilogues
 
 constexpr int LROW = 128;                  // bytes per LDS row (one k-tile, unpadded: DMA is lane-linear)
 
@@ -218,13 +219,13 @@ __device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0,
 __device__ __forceinline__ float2 ln_finish(float mu_sum, float m2_sum, float sq_sum, int G, int K, float eps) {
   const float mu = mu_sum / (float)G;
   const float between = fmaxf(fmaf(-(float)G * mu, mu, sq_sum), 0.f);
-  const float m2 = fmaf((float)LN_GROUP, between, m2_sum);
+  const float m2 = fmaf((float)(K / G), between, m2_sum);          // K / G = columns per group
   return make_float2(mu, rsqrtf(m2 / (float)K + eps));
 }
 template <typename CF>
 __device__ __forceinline__ void ln_row_stats(const GemmParams& p, char* smem, int m0) {
   float2* row_stats = reinterpret_cast<float2*>(smem + CF::SMEM);
-  const int G = p.K / LN_GROUP;
+  const int G = p.K / p.ln_group;
   for (int r = threadIdx.x; r < CF::BM; r += CF::THREADS) {
     const float2* ps = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)min(m0 + r, p.M - 1) * G;
     float mu = 0.f, m2 = 0.f, sq = 0.f;
@@ -797,6 +798,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 
 #include "gemm_w4.inc"
 #include "gemm_w4g.inc"
+#include "gemm_w4k.inc"
 
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
@@ -823,6 +825,17 @@ int launch_cfg(const GemmParams& p, hipStream_t s) {
 // shape heuristic (measured on MI355X, tools/bench_gemm.py): see the Cfg comments
 template <typename TIn, typename TOut, int EPI>
 int launch(const GemmParams& p, hipStream_t s) {
+  // N = 768-class GEMMs with a residual epilogue (out-proj, c_proj): one round of 224x96 split-k tiles when the caller's
+  // row units allow it (gemm_w4k.inc).  Its row statistics are over 96 columns, the generic epilogues' over 64: the
+  // caller says which it expects (rpo_gemm_args.ln_group) and gets an error instead of the other layout.
+  if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TIn) == 2 && sizeof(TOut) == 4) {
+    W4KPlan kplan;
+    const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+    const bool k_ok = p.split_k == 1 && fits32 && w4k_plan(p, &kplan) && aligned16(p.C) && p.ldc % 4 == 0 &&
+                      (p.ln_stats == nullptr || p.ln_group == CfgW4K::BN);
+    if (k_ok && (p.force_cfg == 11 || p.force_cfg == 0)) return launch_w4k<TIn>(p, s);
+    if (p.force_cfg == 11 || (p.ln_stats != nullptr && p.ln_group != LN_GROUP)) return RPO_E_SHAPE;
+  }
   // measured (tools/bench_gemm.py, profiles/): 256x256 wins for the wide-N forward GEMMs of the image tower
   // (in-proj 31.6 vs 36.1 us); a 4-stage 128x128 variant was slower than 2 stages on every shape
   constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 &&
@@ -843,7 +856,7 @@ int launch(const GemmParams& p, hipStream_t s) {
     // than both (in-proj at B=32: 28.1 vs 34.3 / 29.5 us on one box), so it is what the heuristic picks.
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
     constexpr bool epi_ln = EPI == RPO_EPI_LN_BIAS || EPI == RPO_EPI_LN_BIAS_QGELU;
-    const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK && (!epi_ln || p.K <= 16 * LN_GROUP);
+    const bool w4_ok = ok && fits32 && p.K >= 2 * CfgW4::BK && (!epi_ln || p.K <= 16 * p.ln_group);
     const bool wants_big = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && fills;
     // 224x384 tiles when they cover the output in exactly one round and 256x256 tiles do not (c_fc at B = 32)
     {
@@ -908,6 +921,21 @@ extern "C" int rpo_debug_set_timeline(unsigned long long* buf) {
 }
 #endif
 
+// Which partial-statistics layout a BIAS_RESID producer would write for these shapes / dtypes / row units when the choice
+// is left to the library: 96 when the one-round 224x96 kernel applies, else 64.  Looks at M, N, K, lda, ldw, the dtypes,
+// split_k and the row-unit hint only; nothing is dereferenced.
+extern "C" int rpo_gemm_stats_group(const rpo_gemm_args* a) {
+  if (a == nullptr || a->M <= 0 || a->N <= 0 || a->K <= 0) return RPO_E_BADARG;
+  const bool in16 = a->in_dtype == RPO_BF16 || a->in_dtype == RPO_F16;
+  if (a->epilogue != RPO_EPI_BIAS_RESID || !in16 || a->out_dtype != RPO_F32 || a->split_k > 1) return LN_GROUP;
+  GemmParams p{};
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
+  p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
+  W4KPlan q;
+  const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+  return fits32 && w4k_plan(p, &q) ? CfgW4K::BN : LN_GROUP;
+}
+
 extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return RPO_E_BADARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return RPO_E_BADARG;
@@ -956,6 +984,9 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.out2 = static_cast<char*>(a->out2); p.ldout2 = a->ldout2;
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
   p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
+  p.ln_group = a->ln_group == 0 ? LN_GROUP : a->ln_group;
+  if (p.ln_group != 64 && p.ln_group != 96) return RPO_E_BADARG;
+  if (is_ln && (p.K % p.ln_group != 0)) return RPO_E_SHAPE;
   if (p.seg_rows0 < 0 || p.seg_rows1 < 0 || p.seg1_row0 < 0 || p.seg1_row0 > p.M) return RPO_E_BADARG;
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;

@@ -89,6 +89,7 @@ class Engine:
             self._pack(state_dict, tokens)
             self._alloc()
         self.text_cache_ready = False
+        self._stats_group = {}          # batch size -> columns per partial LayerNorm statistic (64 or 96)
         self._eval_graphs = {}          # batch size -> (captured image tower + head, its static input)
         self.probe = None               # optional callable(name) -> context manager bracketing one launch (bench.py)
         self.text_f_version = -1        # prompts version the cached eval text features belong to
@@ -285,8 +286,20 @@ class Engine:
         ops.img_assemble(x_pre, self.cls, self.pos, self.img_prompt, B, N, K)          # rpo.py:201-204
         ops.layernorm_fwd(x_pre, self.ln_pre[0], self.ln_pre[1], self.x[0][:R])        # rpo.py:206
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
-        st = self.ln_stats[:R]
         fold = self.fold_ln
+        # Row units of the whole-stream GEMMs: one image = N frozen + K prompt rows.  With them c_fc tiles by image
+        # (saved pre-activations spread over all workgroups) and out-proj / c_proj run as one round of 224x96 tiles,
+        # whose row statistics are over 96 columns instead of 64 (rpo_gemm_args.ln_group): grp says which.
+        units = (N, K, Rf)
+        which = os.environ.get("RPO_RESID_UNITS", "all")            # A/B switch: all | c_proj | none
+        u_out, u_proj = (units if which == "all" else None), (units if which in ("all", "c_proj") else None)
+        grps = self._stats_group.get(B)
+        if grps is None:
+            grps = self._stats_group[B] = ((ops.gemm_stats_group(R, dv, dv, self.act, u_out),
+                                            ops.gemm_stats_group(R, dv, 4 * dv, self.act, u_proj)) if fold else (64, 64))
+        g_out, g_proj = grps                 # statistics written by out-proj (read by c_fc) / by c_proj (read by in-proj)
+        stv = lambda grp: self.ln_stats.view(-1)[:R * (dv // grp) * 2].view(R, dv // grp, 2)
+        st_out, st_proj, st64 = stv(g_out), stv(g_proj), self.ln_stats[:R]
         last = len(self.vis) - 1
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
@@ -297,7 +310,8 @@ class Engine:
                 ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
             w_in, b_in = (blk.w_in_ln, blk.b_in_ln) if folded_in else (blk.w_in, blk.b_in)
             epi_in = EPI_LN_BIAS if folded_in else EPI_BIAS
-            lnk = lambda r0, r1, c0, c1: (dict(ln_stats=st[r0:r1], ln_colsum=blk.s_in[c0:c1]) if folded_in else {})
+            lnk = lambda r0, r1, c0, c1: (dict(ln_stats=st_proj[r0:r1], ln_colsum=blk.s_in[c0:c1], ln_group=g_proj)
+                                          if folded_in else {})
             if l < last:
                 # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
                 with self._timed("in_proj"):
@@ -315,28 +329,32 @@ class Engine:
                                       q_first=N)
                 lo = Rf
             timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
-            # tiling hint for c_fc: one image = N frozen + K prompt rows, so the rows whose pre-activations are saved
-            # are spread over all workgroups (rpo_gemm_args.seg_*)
-            units = (N, K, Rf) if lo == 0 else None
+            # the last block works on the prompt rows only: plain tiles, 64-column statistics
+            whole = lo == 0
+            un_o, go, so = (u_out, g_out, st_out) if whole else (None, 64, st64)
+            un_p, gp, sp = (u_proj, g_proj, st_proj) if whole else (None, 64, st64)
+            un = units if whole else None
             # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
-            prod = dict(out2=h[lo:], ln_stats=st[lo:]) if fold else {}
+            prod = dict(out2=h[lo:], ln_stats=so[lo:], ln_group=go) if fold else {}
             with timed("out_proj"):
-                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:], **prod)
+                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:], row_units=un_o,
+                            **prod)
             if fold:
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                                 aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo,
-                                ln_stats=st[lo:], ln_colsum=blk.s_fc, row_units=units)
+                                ln_stats=so[lo:], ln_colsum=blk.s_fc, row_units=un, ln_group=go)
             else:
                 with timed("ln_2"):
                     ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
-                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo, row_units=units)
+                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo, row_units=un)
             # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
-            prod = dict(out2=h[lo:], ln_stats=st[lo:]) if (fold and l < last) else {}
+            prod = dict(out2=h[lo:], ln_stats=sp[lo:], ln_group=gp) if (fold and l < last) else {}
             with timed("c_proj"):
-                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:], **prod)
+                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:], row_units=un_p,
+                            **prod)
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

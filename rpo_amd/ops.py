@@ -51,7 +51,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
             group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0,
             out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
             ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS,
-            row_units: Optional[tuple] = None) -> torch.Tensor:
+            row_units: Optional[tuple] = None, ln_group: int = 0) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
@@ -75,14 +75,29 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     split_stride=split_stride, tile_config=tile_config,
                     out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
+    args.ln_group = ln_group
     if row_units is not None:               # (rows per unit in segment 0, rows per unit in segment 1, first row of segment 1)
         args.seg_rows0, args.seg_rows1, args.seg1_row0 = row_units
     if ln_stats is not None:
         rows = a.shape[0] if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else M
         cols = K if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else N
-        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= rows * (cols // 64) * 2
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= rows * (cols // (ln_group or 64)) * 2
     check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
     return out
+
+
+def gemm_stats_group(M: int, N: int, K: int, dtype: torch.dtype, row_units: Optional[tuple]) -> int:
+    """Columns per partial row statistic a BIAS_RESID producer [M, K] x [N, K]^T -> fp32 writes (rpo_gemm_stats_group)."""
+    if dtype == torch.float32:
+        return 64
+    args = GemmArgs(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, in_dtype=dtype_code(dtype), out_dtype=_lib.RPO_F32,
+                    epilogue=_lib.EPI_BIAS_RESID, split_k=1)
+    if row_units is not None:
+        args.seg_rows0, args.seg_rows1, args.seg1_row0 = row_units
+    g = int(_lib.load().rpo_gemm_stats_group(C.byref(args)))
+    if g < 0:
+        check(g, "rpo_gemm_stats_group")
+    return g
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,

@@ -54,7 +54,7 @@ def test_library_loads_and_probe_layouts():
     """The fragment layouts every MFMA kernel assumes, checked on the device with an
     ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
     o = ops()
-    assert o.version() == 2
+    assert o.version() == 3
     for which, kdim in ((0, 16), (1, 2)):
         g = torch.Generator().manual_seed(which)
         a = torch.randint(-4, 5, (32, kdim), generator=g).float()
@@ -280,6 +280,79 @@ def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
         aux = torch.empty((M - row0, N), device=dev())
         o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0, tile_config=10, row_units=(n0, n1, seg1))
         assert torch.equal(out, res["units"][0]) and torch.equal(aux, res["units"][1]), "LDS race"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("n0,n1,units,K", [(197, 24, 32, 768), (197, 24, 32, 3072), (197, 4, 32, 256), (190, 34, 30, 512),
+                                           (224, 0, 28, 1024)])
+def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
+    """The 224x96 kernel of the N = 768 residual GEMMs (tile_config 11; out-proj / c_proj of the image tower: one row
+    unit x 96 columns per workgroup, the four waves split the contraction): C, the 16-bit copy and the 96-column row
+    statistics against float64; deterministic over 25 launches (fixed reduction order, LDS race screen); a consumer
+    given ln_group = 96 reproduces quickgelu(LN(C) W^T + b); layouts that do not fit are refused, not approximated."""
+    from rpo_amd import _lib as L
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    N = 768
+    seg1 = n0 * units
+    M = seg1 + n1 * units
+    hint = (n0, n1, seg1)
+    dt = DT[mode]
+    a, w, bias = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    resid = rnd((M, N), 4, 2.0) + 0.4
+    ad, wd, bd, rd = a.to(dev(), dt), w.to(dev(), dt), bias.to(dev()), resid.to(dev())
+
+    def run(cfg, group, units_hint=hint):
+        c = torch.full((M, N), float("nan"), device=dev())
+        c2 = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        st = torch.full((M, N // group, 2), float("nan"), device=dev())
+        o.gemm_nt(ad, wd, c, L.EPI_BIAS_RESID, bias=bd, resid=rd, out2=c2, ln_stats=st, tile_config=cfg,
+                  row_units=units_hint, ln_group=group)
+        return c, c2, st
+
+    c, c2, st = run(11, 96)
+    ref = q(a, mode) @ q(w, mode).t() + bias.double() + resid.double()
+    close(c, ref, "f32", "224x96 split-k C", tol=1e-4)
+    assert torch.equal(c2.cpu(), c.cpu().to(dt)), "out2 must be the RNE act-dtype copy of C"
+    grp = c.double().cpu().reshape(M, N // 96, 96)
+    ref_st = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1)
+    close(st, ref_st, "f32", "96-column partial row statistics", tol=2e-5)
+    c0, c20, st0 = run(0, 96)                      # the heuristic picks the same kernel
+    assert torch.equal(c0, c) and torch.equal(c20, c2) and torch.equal(st0, st)
+    for _ in range(25):
+        cr, c2r, str_ = run(11, 96)
+        assert torch.equal(cr, c) and torch.equal(c2r, c2) and torch.equal(str_, st), "not deterministic: LDS race"
+    # the generic tiles agree to fp32 summation-order noise and keep their own 64-column layout
+    cg, _, stg = run(6, 64)
+    close(cg, c.double().cpu(), "f32", "64x128 tiles vs 224x96", tol=2e-5)
+    assert stg.shape[1] == N // 64
+    with pytest.raises(RPOLibraryError):
+        run(6, 96)                                 # a generic kernel cannot write 96-column statistics
+    with pytest.raises(RPOLibraryError):
+        run(11, 96, units_hint=None)               # no row units: the kernel does not apply
+    with pytest.raises(RPOLibraryError):
+        run(11, 64)                                # ... and it cannot write 64-column statistics
+    # consumer side with ln_group = 96
+    if K == 768:
+        Nc = 3072
+        wc, bc = rnd((Nc, N), 5, N ** -0.5), rnd((Nc,), 6)
+        gamma, beta = rnd((N,), 7, 0.1) + 1.0, rnd((N,), 8, 0.05)
+        wq = (wc.double() * gamma.double()[None, :]).float().to(dt)
+        sc = wq.double().sum(1).float()
+        bq = (bc.double() + wc.double() @ beta.double()).float()
+        x64 = c.double().cpu()
+        mu = x64.mean(1, keepdim=True)
+        rstd = (x64.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        pre = ((x64 - mu) * rstd * gamma.double() + beta.double()) @ wc.double().t() + bc.double()
+        outs = []
+        for cfg in (0, 10, 8, 2):
+            y = torch.full((M, Nc), float("nan"), dtype=dt, device=dev())
+            o.gemm_nt(c2, wq.to(dev()), y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), ln_stats=st, ln_colsum=sc.to(dev()),
+                      tile_config=cfg, row_units=hint, ln_group=96)
+            outs.append(y)
+        close(outs[0], R.qgelu(pre), mode, "LN-folded c_fc from 96-column statistics", tol=1.5 * TOL[mode])
+        for y in outs[1:]:
+            assert torch.equal(y, outs[0])
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])

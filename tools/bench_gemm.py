@@ -45,6 +45,8 @@ for name, M, N, K, epi, odt, split in SHAPES:
     kw = dict(bias=bias if epi in (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID) else None,
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
+    if M == 7072 and os.environ.get("BENCH_NO_UNITS") != "1":
+        kw["row_units"] = (197, 24, 6304)              # the image tower's layout: one image = 197 frozen + 24 prompt rows
     res = []
     cfgs = [int(c) for c in os.environ.get('BENCH_CFGS', '').split(',') if c] if (ONLY is not None or 'BENCH_CFGS' in os.environ) else [2, 5, 6]
     for cfg in [0] + cfgs:

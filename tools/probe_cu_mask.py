@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Does confining the prompt-row chains (text tower) to a few CUs remove their interference with the image tower?
+
+The step runs text fwd | image fwd -> head -> text bwd | image bwd on two streams.  Alone, image fwd takes ~2.22 ms
+and text fwd ~0.66 ms; together ~2.45 ms.  The round-1 probe tried stream priorities (no effect).  Here the side
+stream is created with hipExtStreamCreateWithCUMask (N CUs, spread over the XCDs or packed) and the same graphs are
+replayed on it.  Reported: each pair alone and together, for several masks, plus whole steps through the trainer with
+the masked side stream.
+"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from rpo_amd import synth
+from rpo_amd.config import vit_b16
+from rpo_amd.trainer import RPO
+
+cfg = vit_b16()
+toks = synth.default_tokens(cfg)
+sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=32, num_batches=10**9)
+img = torch.randn(32, 3, 224, 224, device="cuda"); lab = torch.zeros(32, dtype=torch.int64, device="cuda")
+for _ in range(3): tr.step_async(img, lab)
+torch.cuda.synchronize()
+
+hip = None
+for name in ("libamdhip64.so.7", "libamdhip64.so", "libamdhip64.so.6"):
+    try:
+        hip = ctypes.CDLL(name); break
+    except OSError:
+        pass
+assert hip is not None and hasattr(hip, "hipExtStreamCreateWithCUMask")
+hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+hip.hipExtStreamCreateWithCUMask.restype = ctypes.c_int
+
+
+def masked_stream(bits):
+    words = (ctypes.c_uint32 * 8)(*([0] * 8))
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(h.value)
+
+
+def wall(fn, reps=5):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        ts.append(1e6 * (time.perf_counter() - t0))
+    return sorted(ts)[len(ts) // 2]
+
+
+def pair(g_main, g_side, side):
+    def run():
+        with torch.cuda.stream(side): g_side.replay()
+        g_main.replay()
+    return wall(run)
+
+
+def alone(g, stream=None):
+    def run():
+        if stream is None: g.replay()
+        else:
+            with torch.cuda.stream(stream): g.replay()
+    return wall(run)
+
+
+print(f"alone, unmasked: img_fwd {alone(tr._g_img_fwd):7.1f}  text_fwd {alone(tr._g_text_fwd):7.1f}  "
+      f"img_bwd {alone(tr._g_img_bwd):7.1f}  text_bwd {alone(tr._g_text_bwd):7.1f} us")
+plain = torch.cuda.Stream()
+print(f"side stream unmasked          : text_fwd alone {alone(tr._g_text_fwd, plain):7.1f}  fwd pair {pair(tr._g_img_fwd, tr._g_text_fwd, plain):7.1f}"
+      f"  text_bwd alone {alone(tr._g_text_bwd, plain):7.1f}  bwd pair {pair(tr._g_img_bwd, tr._g_text_bwd, plain):7.1f} us")
+masks = {}
+for n in (8, 16, 32, 64):
+    masks[f"{n:3d} CUs, bits spread (i*{256 // n})"] = [i * (256 // n) for i in range(n)]
+    masks[f"{n:3d} CUs, bits packed (0..{n - 1})"] = list(range(n))
+best = None
+for name, bits in masks.items():
+    s = masked_stream(bits)
+    ta, fp = alone(tr._g_text_fwd, s), pair(tr._g_img_fwd, tr._g_text_fwd, s)
+    tb, bp = alone(tr._g_text_bwd, s), pair(tr._g_img_bwd, tr._g_text_bwd, s)
+    print(f"side = {name:28s}: text_fwd alone {ta:7.1f}  fwd pair {fp:7.1f}  text_bwd alone {tb:7.1f}  bwd pair {bp:7.1f} us")
+    if best is None or fp + bp < best[0]:
+        best = (fp + bp, name, s)
+
+# whole steps through the trainer with the best masked stream in place of the engine's side stream
+def steps(n=30):
+    for _ in range(5): tr.step_async(img, lab)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): tr.step_async(img, lab)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+print(f"whole step, engine's own side stream: {steps():.3f} ms")
+old = tr.engine.side
+tr.engine.side = best[2]
+print(f"whole step, side = {best[1]}: {steps():.3f} ms")
+tr.engine.side = old
+print(f"whole step, engine's own side stream again: {steps():.3f} ms")
