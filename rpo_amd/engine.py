@@ -136,7 +136,7 @@ class Engine:
     def _pack(self, sd, tokens) -> None:
         cfg = self.cfg
         self.vis = [self._block(sd, f"visual.transformer.resblocks.{l}.", fold=self.fold_ln) for l in range(cfg.layers_v)]
-        self.txt = [self._block(sd, f"transformer.resblocks.{l}.") for l in range(cfg.layers_t)]
+        self.txt = [self._block(sd, f"transformer.resblocks.{l}.", fold=self.fold_ln) for l in range(cfg.layers_t)]
         self.kpatch = _round_up(cfg.patch_dim, self.kmult)
         conv = torch.zeros(cfg.d_v, self.kpatch, device=self.dev)
         conv[:, :cfg.patch_dim] = self._f32(sd["visual.conv1.weight"]).reshape(cfg.d_v, -1)
@@ -195,6 +195,7 @@ class Engine:
         self.text_f = f32(Rt, e)
         self.d_text_f = f32(Rt, e)
         self.d_text_f_a = a(Rt, e)
+        self.ln_stats_t = f32(Rt, dt // 64, 2)
         self.dy_t = f32(max(SPLIT_FC, SPLIT_Q), Rt, dt)
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
@@ -260,17 +261,30 @@ class Engine:
         cfg = self.cfg
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         ops.broadcast_rows(self.text_prompt, self.xt[0], n)          # trainers/rpo.py:176-177
+        fold, st, last = self.fold_ln and os.environ.get("RPO_NO_TEXT_FOLD") != "1", self.ln_stats_t, len(self.txt) - 1
         for l, blk in enumerate(self.txt):
             kv = self.kv_t[l]
-            ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
-            ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt])
+            # LayerNorm folded into the GEMMs around it exactly as in the image tower (_image_forward): the residual
+            # GEMMs leave the 16-bit copy of their result in ht and its row statistics in st
+            if fold and l > 0:
+                ops.gemm_nt(self.ht, blk.w_in_ln[:dt], self.qt[l], EPI_LN_BIAS, bias=blk.b_in_ln[:dt], ln_stats=st,
+                            ln_colsum=blk.s_in[:dt])
+            else:
+                ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
+                ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt])
             ops.text_attn_fwd(self.qt[l], kv[:, :dt], kv[:, dt:], self.att_t, self.len_i32, n, K, self.Lmax, H,
                               causal=False, scale=SCALE)
-            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l])
-            ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
-            ops.gemm_nt(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
-                        aux=self.ut[l] if train else None, aux_row0=0)
-            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l])
+            prod = dict(out2=self.ht, ln_stats=st) if fold else {}
+            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod)
+            if fold:
+                ops.gemm_nt(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                            aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc)
+            else:
+                ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
+                ops.gemm_nt(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
+                            aux=self.ut[l] if train else None, aux_row0=0)
+            prod = dict(out2=self.ht, ln_stats=st) if (fold and l < last) else {}
+            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod)
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
         ops.gemm_nt(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 

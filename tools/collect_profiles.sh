@@ -30,6 +30,7 @@ timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench
 timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
+timeout 300 python tools/probe_cu_mask.py 2>&1 | grep -v amdgpu.ids > $O/cu_mask_probe.txt
 timeout 100 python tools/probe_per_layer.py > $O/per_layer_probe.txt 2>&1
 BENCH_CFGS=2,3,7,8,10 timeout 200 python tools/bench_gemm.py > $O/bench_gemm.txt 2>&1
 [ -x tools/build/ubench_dma ] && timeout 100 tools/build/ubench_dma > $O/ubench_dma.txt 2>&1

@@ -97,3 +97,23 @@ tr.engine.side = best[2]
 print(f"whole step, side = {best[1]}: {steps():.3f} ms")
 tr.engine.side = old
 print(f"whole step, engine's own side stream again: {steps():.3f} ms")
+
+# --- is the interference about CUs at all?  Replace the text graph by 84 one-workgroup kernels (nothing to contend for
+# but the command processor / the dependent-launch path) and by 84 x 64-workgroup LDS-free kernels.
+from rpo_amd import ops
+tiny_p, tiny_g, tiny_b = (torch.zeros(256, device="cuda") for _ in range(3))
+mid_p, mid_g, mid_b = (torch.zeros(64 * 256 * 64, device="cuda") for _ in range(3))
+def cap(fn):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+for _ in range(2):
+    ops.sgd_step(tiny_p, tiny_g, tiny_b, 0.0, 0.0, 0.0, 1.0, first_step=False)
+    ops.sgd_step(mid_p, mid_g, mid_b, 0.0, 0.0, 0.0, 1.0, first_step=False)
+g_tiny = cap(lambda: [ops.sgd_step(tiny_p, tiny_g, tiny_b, 0.0, 0.0, 0.0, 1.0, first_step=False) for _ in range(84)])
+g_mid = cap(lambda: [ops.sgd_step(mid_p, mid_g, mid_b, 0.0, 0.0, 0.0, 1.0, first_step=False) for _ in range(84)])
+print(f"84 one-workgroup kernels alone {alone(g_tiny, plain):7.1f} us; image fwd beside them {pair(tr._g_img_fwd, g_tiny, plain):7.1f} us "
+      f"(image fwd alone {alone(tr._g_img_fwd):7.1f})")
+print(f"84 x 4096-workgroup streaming kernels (no LDS) alone {alone(g_mid, plain):7.1f} us; image fwd beside them "
+      f"{pair(tr._g_img_fwd, g_mid, plain):7.1f} us")

@@ -18,9 +18,9 @@ if db:
                 "# NB: kernel tracing serialises the two HIP queues; per-kernel durations are valid, overlap is not.\n")
         f.write(txt + "\n# last step:\n" + tl)
 SH = {"qkv": "in-proj 7072x2304x768 bias (gemm_w4_kernel: 256x256 tiles, one wave per SIMD, asm k-loop), 25.0 GFLOP, algorithmic bytes 10.9+3.5+32.6 MB",
-      "out_proj": "out-proj 7072x768x768 bias+residual (gemm_nt_kernel, 64x128 tiles), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
+      "out_proj": "out-proj 7072x768x768 bias+residual (gemm_w4k_kernel: 224x96 tiles, waves split k), 8.3 GFLOP, 10.9+1.2+21.7+21.7 MB",
       "c_fc": "c_fc 7072x3072x768 bias+QuickGELU (gemm_w4g_kernel: 224x384 tiles, one round of 256 workgroups), 33.4 GFLOP, 10.9+4.7+43.4 MB",
-      "c_proj": "c_proj 7072x768x3072 bias+residual (gemm_nt_kernel, 64x128 tiles), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
+      "c_proj": "c_proj 7072x768x3072 bias+residual (gemm_w4k_kernel: 224x96 tiles, waves split k), 33.4 GFLOP, 43.4+4.7+21.7+21.7 MB"}
 lines = ["# PMC counters per launch (mean over launches) of the four forward GEMMs of one image-tower block at B=32,\n"
          "# from separate `rocprofv3 --kernel-trace --pmc <set>` passes over `tools/bench_gemm.py --only <shape>`.\n"
          "# FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x.\n"
@@ -36,7 +36,7 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if any(k in r["Kernel_Name"] for k in ("gemm_nt_kernel", "gemm_pp_kernel", "gemm_w4_kernel", "gemm_w4g_kernel")):
+            if any(k in r["Kernel_Name"] for k in ("gemm_nt_kernel", "gemm_pp_kernel", "gemm_w4_kernel", "gemm_w4g_kernel", "gemm_w4k_kernel")):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, x in agg.items():
             vals[k] = sum(x) / len(x)
@@ -114,7 +114,7 @@ for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_f1
     src = os.path.join(raw, fn)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
-for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt"):
+for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt", "cu_mask_probe.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
