@@ -12,7 +12,8 @@
  * Conventions
  *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless noted
  *   - the caller (PyTorch-ROCm) allocates and owns every buffer; nothing here
- *     allocates, frees or keeps global mutable state
+ *     allocates, frees or keeps state a caller could observe (the one internal cache: an atomic per-kernel
+ *     "large-LDS attribute already set on device d" bit in front of an idempotent hipFuncSetAttribute)
  *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as
  *     void*; 0 = the null stream) and returns immediately
  *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = RPO_E_* argument
@@ -181,10 +182,18 @@ int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int6
 
 /* Backward of the above for the prompt rows only: dq[B*Kp, lddq] given da[B*Kp, ldda].
  * q_rows points at the first PROMPT row of q; k, v at the first frozen row.  dK/dV are not
- * produced: keys/values belong to frozen tokens.  Kp <= 64, N <= 288. */
+ * produced: keys/values belong to frozen tokens.  Kp <= 128, N <= 288. */
 int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                           const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
                           int B, int H, int N, int Kp, float scale, void* stream);
+
+/* The same with the d out-proj GEMM folded in (16-bit storage, d = H * 64 = 512 or 768, Kp <= 32): dx[B*Kp, lddx] is the gradient
+ * of the out-proj OUTPUT (act dtype) and w_out_t[d, ldw] the transposed out-proj weight ([in, out], as packed for the
+ * dX GEMMs); every (image, head) workgroup forms its slice of da = dx . W_out itself.  Replaces the autograd of
+ * out_proj + SDPA (clip/model.py:186) for the prompt rows with one launch. */
+int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                               const void* dx, int64_t lddx, const void* w_out_t, int64_t ldw, void* dq, int64_t lddq,
+                               int dtype, int B, int H, int N, int Kp, float scale, void* stream);
 
 /* Text-tower attention for `rows` query rows per class against that class's cached keys /
  * values kc, vc [n_cls * Lmax, ldkv] (class c uses rows c*Lmax .. c*Lmax + len[c]).

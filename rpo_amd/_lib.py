@@ -69,6 +69,8 @@ SIGNATURES = {
                                       c_f32, c_vp]),
     "rpo_attn_readonly_fwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32,
                                       c_f32, c_i32, c_vp]),
+    "rpo_attn_readonly_bwd_proj": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32,
+                                           c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_attn_readonly_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                       c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_text_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32,

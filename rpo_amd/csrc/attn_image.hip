@@ -214,6 +214,27 @@ __device__ __forceinline__ f32x16_t tile_times_frag(const char* lds, int t, cons
   return acc;
 }
 
+// Same product with the frag operand given in "C/D order": cd[ks] = pack8 of registers 8*(ks&1) .. +7 of the 32x32 MFMA
+// result tile ks>>1 whose ROWS are this contraction's index, i.e. lane (q, half) holds elements
+// j = 16*ks + 4*half + {0..3} and 16*ks + 8 + 4*half + {0..3}.  A k-order applied to both operands cancels, so the LDS
+// rows are read as the same two 8-byte pieces -- no lane exchange between the MFMA that produced cd and this one.
+template <typename T>
+__device__ __forceinline__ f32x16_t tile_times_cdfrag(const char* lds, int t, const bf16x8_t (&cd)[4], int l31, int half) {
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const char* rowp = lds + (32 * t + l31) * 144 + half * 8;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(rowp + ks * 32), hi = *reinterpret_cast<const u32x2*>(rowp + ks * 32 + 16);
+    u32x4 a; a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
+    acc = mfma16<T>(__builtin_bit_cast(bf16x8_t, a), cd[ks], acc);
+  }
+  return acc;
+}
+
 // keys >= N of tile t -> -inf (only tiles that can hold padding pay for the compare), then the tile's row
 // maximum over both lane halves.  A lane holds one query's scores for 16 of the tile's 32 keys.
 __device__ __forceinline__ float mask_and_max(f32x16_t& s, int t, int N, int half) {
@@ -402,12 +423,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 // The 4 waves of the workgroup share one 32-query tile: each recomputes the (cheap) score tile row
 // statistics, then takes the key tiles t = wave, wave+4, ... for dP / U / W; partial U, W, delta are
 // combined through LDS (the staging area is dead by then).
-template <typename T, int NT>
+//
+// NCW > 0 (16-bit storage): the d out-proj GEMM is folded in.  `da` then is d(out-proj output) [B*Kp, d] (d = 256 * NCW)
+// and `wo` the transposed out-proj weight [d (in), d (out)]: the workgroup first forms its head's slice
+// da_h = da . W_out[:, 64h .. 64h+63] -- 32 x 64 x d on the matrix cores, the four waves taking d / 4 of the contraction
+// each, operands straight from global memory in one batch with the K / V staging loads, partial tiles summed through LDS
+// before K / V land there -- and feeds it to the dP MFMAs in the layout the result tile already has
+// (tile_times_cdfrag).  One launch and one [B*Kp, d] round trip per block less on the backward chain.
+template <typename T, int NT, int NCW = 0>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
                                                        const T* __restrict__ k, const T* __restrict__ v,
                                                        int64_t ldkv, const T* __restrict__ da, int64_t ldda,
                                                        T* dq, int64_t lddq, int B, int H, int N, int Kp,
-                                                       float scale) {
+                                                       float scale, const T* __restrict__ wo = nullptr,
+                                                       int64_t ldwo = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -424,17 +453,85 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
   bf16x8_t i0, i1;
   if constexpr (sizeof(T) == 2) { i0 = ident_frag<T>(0, l31, half); i1 = ident_frag<T>(1, l31, half); }
 
-  const int nqt = (Kp + 31) / 32;
+  // fused variant: one query tile (the launcher checks Kp <= 32) -- with a runtime trip count hipcc hoists the address
+  // arithmetic of every load of the prologue out of the loop and spills it
+  const int nqt = NCW > 0 ? 1 : (Kp + 31) / 32;
   for (int qt = 0; qt < nqt; ++qt) {
     if (qt > 0) __syncthreads();                   // partials of the previous tile have been consumed
     const int i = qt * 32 + l31;
     const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
     RowFrag<T> qf, df;                             // issued ahead of the staging loads: one HBM round trip
     qf.load(qr + prow * ldq + h * 64, half);
-    df.load(da + prow * ldda + h * 64, half);
-    if constexpr (sizeof(T) == 2) {
+    bf16x8_t dcd[4];                               // fused path: da_h of this lane's query in C/D order
+    if constexpr (NCW > 0) {
+      static_assert(sizeof(T) == 2, "the fused d out-proj needs 16-bit storage");
+      // operands of this wave's NCW 64-deep chunks of the contraction (chunks wave, wave + 4, ...), all in flight
+      bf16x8_t wa[2][NCW][4], xb[NCW][4];
+      // three row pointers; everything else is a compile-time offset (immediate field of the load)
+      const T* xrow = da + prow * ldda + half * 8 + 64 * wave;
+      const T* wrow0 = wo + (int64_t)(h * 64 + l31) * ldwo + half * 8 + 64 * wave;
+      const T* wrow1 = wrow0 + 32 * ldwo;
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          constexpr int dummy = 0; (void)dummy;
+          xb[c][kk] = *reinterpret_cast<const bf16x8_t*>(xrow + (256 * c + 16 * kk));
+          wa[0][c][kk] = *reinterpret_cast<const bf16x8_t*>(wrow0 + (256 * c + 16 * kk));
+          wa[1][c][kk] = *reinterpret_cast<const bf16x8_t*>(wrow1 + (256 * c + 16 * kk));
+        }
+      f32x16_t dpart[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpart[jt][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) dpart[jt] = mfma16<T>(wa[jt][c][kk], xb[c][kk], dpart[jt]);
+      }
+      // K / V rows are requested only now -- the 144 operand registers above are dead, the kernel runs two waves per
+      // SIMD on 256 registers -- and written to LDS once the partial tiles have been exchanged through it
+      constexpr int CHUNKS = NT * 32 * 8, ITERS = (CHUNKS + 255) / 256;
+      uint4 ka[ITERS], va[ITERS];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {         // unconditional (clamped) loads: a branch per load serialises them
+        const int id = tid + it * 256, key = min(id >> 3, N - 1), c = id & 7;
+        ka[it] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * ldkv + c * 8);
+        va[it] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ldkv + c * 8);
+      }
+      float4* px = reinterpret_cast<float4*>(smem);                // [4 waves][8][64 lanes]
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        px[(wave * 8 + i) * 64 + lane] = make_float4(dpart[i >> 2][4 * (i & 3)], dpart[i >> 2][4 * (i & 3) + 1],
+                                                     dpart[i >> 2][4 * (i & 3) + 2], dpart[i >> 2][4 * (i & 3) + 3]);
+      __syncthreads();
+      float dfull[32];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 a = px[i * 64 + lane], b = px[(8 + i) * 64 + lane], c = px[(16 + i) * 64 + lane],
+                     d = px[(24 + i) * 64 + lane];
+        dfull[4 * i] = (a.x + b.x) + (c.x + d.x); dfull[4 * i + 1] = (a.y + b.y) + (c.y + d.y);
+        dfull[4 * i + 2] = (a.z + b.z) + (c.z + d.z); dfull[4 * i + 3] = (a.w + b.w) + (c.w + d.w);
+      }
+#pragma unroll
+      for (int ks2 = 0; ks2 < 4; ++ks2) dcd[ks2] = pack8<T>(dfull + 8 * ks2);
+      __syncthreads();                             // the partials have been read: K / V may land on them
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int id = tid + it * 256, key = id >> 3, c = id & 7;
+        if (id < CHUNKS) {
+          const bool live = key < N;               // rows past the last key: zeros
+          *reinterpret_cast<uint4*>(ks + key * 144 + c * 16) = live ? ka[it] : make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(vs + key * 144 + c * 16) = live ? va[it] : make_uint4(0, 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
+      df.load(da + prow * ldda + h * 64, half);
       stage2_bf16<NT, 256>(ks, vs, reinterpret_cast<const bf16_t*>(kb), reinterpret_cast<const bf16_t*>(vb), ldkv, N, tid);          // K and V loads in ONE round trip
     } else {
+      df.load(da + prow * ldda + h * 64, half);
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(ks), kb, ldkv, N, tid);
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
     }
@@ -465,7 +562,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
       f32x16_t pt = tile_times_frag<T>(ks, t, qf, l31v, half);
       (void)mask_and_max(pt, t, N, half);
       (void)exp_tile<T>(pt, m, scale);
-      f32x16_t dp = tile_times_frag<T>(vs, t, df, l31v, half);
+      f32x16_t dp;
+      if constexpr (NCW > 0) dp = tile_times_cdfrag<T>(vs, t, dcd, l31v, half);
+      else dp = tile_times_frag<T>(vs, t, df, l31v, half);
       if constexpr (sizeof(T) == 2) {
         const char* krow = ks + (32 * t + l31v) * 144 + half * 16;
         bf16x8_t krows[4];
@@ -534,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
 template <typename T, int NT>
 int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
                int N, int Kp, float scale, int q_first, hipStream_t s) {
-  static unsigned long long lds_ok = 0;
+  static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_fwd_kernel<T, NT>;
   constexpr int bytes = AL<T, NT>::FWD_BYTES;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
@@ -547,14 +646,38 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
 template <typename T, int NT>
 int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* da,
                int64_t ldda, void* dq, int64_t lddq, int B, int H, int N, int Kp, float scale, hipStream_t s) {
-  static unsigned long long lds_ok = 0;
+  static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT>;
   constexpr int bytes = AL<T, NT>::BWD_BYTES;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
-                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale);
+                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(nullptr), (int64_t)0);
   return rpo_launch_status();
+}
+
+template <typename T, int NT, int NCW>
+int launch_bwd_proj(const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dx,
+                    int64_t lddx, const void* wo, int64_t ldwo, void* dq, int64_t lddq, int B, int H, int N, int Kp,
+                    float scale, hipStream_t s) {
+  static rpo_lds_mask_t lds_ok{0};
+  auto kern = attn_bwd_kernel<T, NT, NCW>;
+  constexpr int bytes = AL<T, NT>::BWD_BYTES;
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
+                     static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(dx), lddx,
+                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(wo), ldwo);
+  return rpo_launch_status();
+}
+template <typename T>
+int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                      const void* dx, int64_t lddx, const void* wo, int64_t ldwo, void* dq, int64_t lddq, int B, int H,
+                      int N, int Kp, float scale, hipStream_t s) {
+#define RPO_BP(NT_, NCW_) return launch_bwd_proj<T, NT_, NCW_>(qr, ldq, k, v, ldkv, dx, lddx, wo, ldwo, dq, lddq, B, H, N, Kp, scale, s)
+  if (ncw == 2) { if (big) RPO_BP(9, 2); RPO_BP(7, 2); }
+  if (ncw == 3) { if (big) RPO_BP(9, 3); RPO_BP(7, 3); }
+#undef RPO_BP
+  return RPO_E_SHAPE;
 }
 
 bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
@@ -615,4 +738,21 @@ extern "C" int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void
   }
   if (N <= 224) return launch_bwd<float, 7>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
   return launch_bwd<float, 9>(q_rows, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, s);
+}
+
+extern "C" int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
+                                          const void* dx, int64_t lddx, const void* w_out_t, int64_t ldw, void* dq,
+                                          int64_t lddq, int dtype, int B, int H, int N, int Kp, float scale,
+                                          void* stream) {
+  if (!q_rows || !k || !v || !dx || !w_out_t || !dq || B <= 0 || H <= 0 || N <= 0 || Kp <= 0) return RPO_E_BADARG;
+  if (dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
+  const int d = H * 64;
+  if (N > 288 || Kp > 32 || (d != 512 && d != 768)) return RPO_E_SHAPE;
+  if (!aligned16(q_rows) || !aligned16(k) || !aligned16(v) || !aligned16(dx) || !aligned16(w_out_t) || !ok_ld(ldq, 2) ||
+      !ok_ld(ldkv, 2) || !ok_ld(lddx, 2) || !ok_ld(ldw, 2) || reinterpret_cast<uintptr_t>(dq) % 8 || (lddq * 2) % 8)
+    return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16)
+    return dispatch_bwd_proj<bf16_t>(d / 256, N > 224, q_rows, ldq, k, v, ldkv, dx, lddx, w_out_t, ldw, dq, lddq, B, H, N, Kp, scale, s);
+  return dispatch_bwd_proj<f16_t>(d / 256, N > 224, q_rows, ldq, k, v, ldkv, dx, lddx, w_out_t, ldw, dq, lddq, B, H, N, Kp, scale, s);
 }

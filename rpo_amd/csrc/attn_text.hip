@@ -120,7 +120,7 @@ template <typename T, bool BWD>
 int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
            int64_t ldda, void* out, int64_t ldo, const int32_t* len, int n_cls, int rows, int Lmax, int H,
            int causal, float scale, hipStream_t s) {
-  static unsigned long long lds_ok = 0;
+  static rpo_lds_mask_t lds_ok{0};
   auto kern = text_attn_kernel<T, BWD>;
   const int bytes = 2 * Lmax * 65 * 4;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), 2 * 128 * 65 * 4, &lds_ok)) return rc;

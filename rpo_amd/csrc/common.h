@@ -1,6 +1,7 @@
 // Shared device helpers for librpo_hip.so (gfx950 only: wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/rpo_amd.h"
@@ -113,15 +114,19 @@ __device__ __forceinline__ float quick_gelu_grad(float u) {
 
 // Kernels that need more than 64 KiB of dynamic LDS must raise the limit once per (kernel, device).  `mask` is the
 // caller's function-local static: bit d = done on device d (devices >= 64 re-set it on every launch).
-static inline int rpo_allow_lds(const void* kern, int bytes, unsigned long long* mask) {
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once per device.  The per-kernel "already done on
+// device d" bits are the library's only mutable state: an atomic cache of an idempotent driver call (a lost race repeats
+// the call, nothing else), not something a caller can observe.
+using rpo_lds_mask_t = std::atomic<unsigned long long>;
+static inline int rpo_allow_lds(const void* kern, int bytes, rpo_lds_mask_t* mask) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
-  if (bit && (*mask & bit)) return 0;
+  if (bit && (mask->load(std::memory_order_relaxed) & bit)) return 0;
   e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return (int)e;
-  *mask |= bit;
+  mask->fetch_or(bit, std::memory_order_relaxed);
   return 0;
 }
 

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
-  static unsigned long long lds_ok = 0;
+  static rpo_lds_mask_t lds_ok{0};
   auto kern = gemm_pp_kernel<TOut, EPI>;
   constexpr int smem_bytes = CfgPP::SMEM + CfgPP::BM * 8;     // + (mu, rstd) per row of the LayerNorm-fold epilogues
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), smem_bytes, &lds_ok)) return rc;
@@ -813,7 +813,7 @@ int launch_pp(const GemmParams& p, hipStream_t s) {
 
 template <typename TIn, typename TOut, int EPI, typename CF>
 int launch_cfg(const GemmParams& p, hipStream_t s) {
-  static unsigned long long lds_ok = 0;
+  static rpo_lds_mask_t lds_ok{0};
   auto kern = gemm_nt_kernel<TIn, TOut, EPI, CF>;
   constexpr int smem_bytes = CF::SMEM + CF::BM * 8;           // + (mu, rstd) per row of the LayerNorm-fold epilogues
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), smem_bytes, &lds_ok)) return rc;

@@ -374,7 +374,7 @@ class Engine:
 
     # ------------------------------------------------------------------ backward pieces
     def _rows_backward(self, blocks: List[_Block], x: List[torch.Tensor], xm: List[torch.Tensor],
-                       u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd) -> torch.Tensor:
+                       u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd, fold_out: bool = False) -> torch.Tensor:
         """Shared by both towers: dx (fp32, in dxa) holds dL/d(block output) on entry; on return the
         tensor holding dL/d(block-0 input).  dxc mirrors dx in the act dtype (GEMM A operand)."""
         for l in reversed(range(len(blocks))):
@@ -385,8 +385,11 @@ class Engine:
             ops.layernorm_bwd(dy[:SPLIT_FC], xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
-            ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                          # d out_proj
-            attn_bwd(l, da, dq)
+            if fold_out:
+                attn_bwd(l, a_in, dq)                                             # d out_proj inside the attention kernel
+            else:
+                ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                      # d out_proj
+                attn_bwd(l, da, dq)
             ops.gemm_nt(dq, blk.w_q_t, dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)   # d q-projection
             ops.layernorm_bwd(dy[:SPLIT_Q], x[l], blk.ln1_w, dxb, dxa,
                               None if self.act == torch.float32 else dxc)
@@ -406,13 +409,21 @@ class Engine:
         ops.layernorm_bwd(self.dy_v[0, :Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
+        # 16-bit modes, K <= 32, d = 512 / 768: the d out-proj GEMM runs inside the attention backward kernel
+        fold_out = (self.act != torch.float32 and K <= 32 and dv in (512, 768)
+                    and os.environ.get("RPO_NO_BWD_FOLD") != "1")
+
         def attn_bwd(l, da, dq):
             qkv = self.qkv[l]
-            ops.attn_readonly_bwd(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da, dq, B, H, N, K, SCALE)
+            if fold_out:
+                ops.attn_readonly_bwd_proj(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da,
+                                           self.vis[l].w_out_t, dq, B, H, N, K, SCALE)
+            else:
+                ops.attn_readonly_bwd(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da, dq, B, H, N, K, SCALE)
 
         dx = self._rows_backward(self.vis, [t[Rf:R] for t in self.x[:-1]], [t[Rf:R] for t in self.xm],
                                  [t[:Rp] for t in self.u], dxa, dxb, dxc, self.du_v[:Rp], self.da_v[:Rp],
-                                 self.dq_v[:Rp], self.dy_v[:, :Rp], attn_bwd)
+                                 self.dq_v[:Rp], self.dy_v[:, :Rp], attn_bwd, fold_out=fold_out)
         # through ln_pre (rpo.py:206) to the appended prompt rows, then sum over the batch (.repeat, :204)
         ops.layernorm_bwd(dx, self.x_pre[Rf:R], self.ln_pre[0], None, dxb)
         ops.reduce_groups(dxb, self.g_img, B)

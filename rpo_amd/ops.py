@@ -165,6 +165,16 @@ def attn_readonly_fwd(q, k, v, out, B: int, H: int, N: int, Kp: int, scale: floa
     return out
 
 
+def attn_readonly_bwd_proj(q_rows, k, v, dx, w_out_t, dq, B: int, H: int, N: int, Kp: int, scale: float = 0.125):
+    """attn_readonly_bwd with the d out-proj GEMM folded in: dx = gradient of the out-proj output (act dtype)."""
+    assert q_rows.dtype == k.dtype == v.dtype == dx.dtype == w_out_t.dtype == dq.dtype
+    check(_lib.load().rpo_attn_readonly_bwd_proj(q_rows.data_ptr(), _ld(q_rows), k.data_ptr(), v.data_ptr(), _ld(k),
+                                                 dx.data_ptr(), _ld(dx), w_out_t.data_ptr(), _ld(w_out_t), dq.data_ptr(),
+                                                 _ld(dq), dtype_code(dq.dtype), B, H, N, Kp, scale, _stream()),
+          "rpo_attn_readonly_bwd_proj")
+    return dq
+
+
 def attn_readonly_bwd(q_rows, k, v, da, dq, B: int, H: int, N: int, Kp: int, scale: float = 0.125):
     assert _ld(k) == _ld(v)
     check(_lib.load().rpo_attn_readonly_bwd(q_rows.data_ptr(), _ld(q_rows), k.data_ptr(), v.data_ptr(), _ld(k),

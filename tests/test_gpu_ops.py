@@ -528,6 +528,49 @@ def test_attn_readonly_bwd(mode, B, H, N, Kp):
     close(dq, ref, mode, f"attn bwd B{B} H{H} N{N} K{Kp}", tol=None if mode == "f32" else 3e-2)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,N,Kp", [(2, 12, 197, 24), (3, 8, 50, 7), (1, 12, 257, 32), (2, 8, 197, 1)])
+def test_attn_readonly_bwd_with_out_proj_folded_in(mode, B, H, N, Kp):
+    """rpo_attn_readonly_bwd_proj: dq from the gradient of the out-proj OUTPUT -- every (image, head) workgroup forms
+    da = dx . W_out[:, head] itself.  Against float64 (da rounded to the act dtype as the separate GEMM would), against
+    the two-launch path it replaces, and refused where it does not apply."""
+    from rpo_amd import _lib as L
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    d = 64 * H
+    dt = DT[mode]
+    qkv = _img_rows(B, N, Kp, d, 12)
+    dx, w_out = rnd((B * Kp, d), 13), rnd((d, d), 14, d ** -0.5)          # w_out[out, in] as nn.Linear
+    t = qkv.to(dev(), dt)
+    Rf = B * N
+    w_t = w_out.t().contiguous().to(dev(), dt)                             # [in, out]: the dX-GEMM packing
+    dq = torch.full((B * Kp, d), float("nan"), dtype=dt, device=dev())
+    o.attn_readonly_bwd_proj(t[Rf:, :d], t[:Rf, d:2 * d], t[:Rf, 2 * d:], dx.to(dev(), dt), w_t, dq, B, H, N, Kp)
+    # the path it replaces
+    da = torch.empty((B * Kp, d), dtype=dt, device=dev())
+    o.gemm_nt(dx.to(dev(), dt), w_t, da, L.EPI_NONE)
+    dq2 = torch.full((B * Kp, d), float("nan"), dtype=dt, device=dev())
+    o.attn_readonly_bwd(t[Rf:, :d], t[:Rf, d:2 * d], t[:Rf, 2 * d:], da, dq2, B, H, N, Kp)
+    q64 = q(qkv, mode)
+    da64 = q((q(dx, mode) @ q(w_out, mode)).float(), mode)                 # da[r, j] = sum_o dx[r, o] W[o, j], rounded
+    ref = torch.empty(B * Kp, d, dtype=torch.float64)
+    for b in range(B):
+        fr = slice(b * N, (b + 1) * N)
+        pr = slice(Rf + b * Kp, Rf + (b + 1) * Kp)
+        ref[b * Kp:(b + 1) * Kp] = R.attn_rows_bwd(q64[pr, :d], q64[fr, d:2 * d], q64[fr, 2 * d:],
+                                                   da64[b * Kp:(b + 1) * Kp], H)
+    close(dq, ref, mode, f"attn bwd + d out-proj B{B} H{H} N{N} K{Kp}", tol=3e-2)
+    close(dq, dq2.double().cpu(), mode, "fused vs GEMM + attn bwd", tol=3e-2)
+    for _ in range(10):
+        dq3 = torch.empty_like(dq)
+        o.attn_readonly_bwd_proj(t[Rf:, :d], t[:Rf, d:2 * d], t[:Rf, 2 * d:], dx.to(dev(), dt), w_t, dq3, B, H, N, Kp)
+        assert torch.equal(dq3, dq), "not deterministic: LDS race"
+    if Kp == 24:
+        with pytest.raises(RPOLibraryError):                               # 33 query rows: two query tiles
+            big = torch.empty((B * 33, d), dtype=dt, device=dev())
+            o.attn_readonly_bwd_proj(big, t[:Rf, d:2 * d], t[:Rf, 2 * d:], big, w_t, big.clone(), B, H, N, 33)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_text_attn_fwd_bwd(mode):
     o = ops()
