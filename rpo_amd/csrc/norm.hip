@@ -105,8 +105,19 @@ __global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __re
     if (c < nv4) {
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * c);
       const float4 w = *reinterpret_cast<const float4*>(gamma + 4 * c);
+      // split-K slabs, summed in fixed order.  The first four are fetched unconditionally (clamped index, masked add):
+      // a load inside a loop with a runtime trip count is one memory round trip per slab on a latency-bound chain
       float4 t = load4f<TDY>(dyr + 4 * c);
-      for (int sp = 1; sp < splits; ++sp) {     // split-K slabs, fixed order
+      float4 ts[3];
+#pragma unroll
+      for (int sp = 1; sp < 4; ++sp) ts[sp - 1] = load4f<TDY>(dyr + (int64_t)min(sp, splits - 1) * split_stride + 4 * c);
+#pragma unroll
+      for (int sp = 1; sp < 4; ++sp) {
+        const float m = sp < splits ? 1.0f : 0.0f;
+        t.x = fmaf(m, ts[sp - 1].x, t.x); t.y = fmaf(m, ts[sp - 1].y, t.y);
+        t.z = fmaf(m, ts[sp - 1].z, t.z); t.w = fmaf(m, ts[sp - 1].w, t.w);
+      }
+      for (int sp = 4; sp < splits; ++sp) {
         const float4 t2 = load4f<TDY>(dyr + (int64_t)sp * split_stride + 4 * c);
         t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
       }
