@@ -431,12 +431,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 // before K / V land there -- and feeds it to the dP MFMAs in the layout the result tile already has
 // (tile_times_cdfrag).  One launch and one [B*Kp, d] round trip per block less on the backward chain.
 template <typename T, int NT, int NCW = 0>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ qr, int64_t ldq,
-                                                       const T* __restrict__ k, const T* __restrict__ v,
-                                                       int64_t ldkv, const T* __restrict__ da, int64_t ldda,
+// (No __restrict__ on the inputs: hipcc treats loads through restrict-const pointers as invariant and moves them across
+// the asm memory barriers that pin the order of the fused prologue's loads -- its vmcnt waits are counted.)
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t ldq, const T* k, const T* v,
+                                                       int64_t ldkv, const T* da, int64_t ldda,
                                                        T* dq, int64_t lddq, int B, int H, int N, int Kp,
-                                                       float scale, const T* __restrict__ wo = nullptr,
-                                                       int64_t ldwo = 0) {
+                                                       float scale, const T* wo = nullptr, int64_t ldwo = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -461,63 +461,113 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
     const int i = qt * 32 + l31;
     const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
     RowFrag<T> qf, df;                             // issued ahead of the staging loads: one HBM round trip
+    RPO_STAMP(10);
     qf.load(qr + prow * ldq + h * 64, half);
     bf16x8_t dcd[4];                               // fused path: da_h of this lane's query in C/D order
     if constexpr (NCW > 0) {
       static_assert(sizeof(T) == 2, "the fused d out-proj needs 16-bit storage");
-      // operands of this wave's NCW 64-deep chunks of the contraction (chunks wave, wave + 4, ...), all in flight
-      bf16x8_t wa[2][NCW][4], xb[NCW][4];
-      // three row pointers; everything else is a compile-time offset (immediate field of the load)
+      // This wave's NCW 64-deep chunks of the contraction (chunks wave, wave + 4, ...).  The W_out^T slice (64 rows x 128 B
+      // per chunk) comes in by LDS-DMA into two wave-private 8-KB slots -- whole 128-B lines per 8 lanes, XOR-swizzled
+      // like the GEMM tiles; as per-lane operand loads (32 rows x 32 B per instruction) the same bytes took 16 k cycles --
+      // the dx rows as per-lane fragments, and K / V are requested behind them so that their (cold) latency hides under
+      // the MFMAs.  The order of the groups is pinned (counted vmcnt waits below).
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
+      char* myslot = smem + wave * 16384;
+      const int dr = lane >> 3, dc = lane & 7;
+      const char* wsrc = reinterpret_cast<const char*>(wo) + ((int64_t)(h * 64 + dr) * ldwo) * 2 + 128 * wave;
+      auto dma_chunk = [&](int c, int slot) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int sw = ((8 * i + dr) >> 1) & 7;
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(8 * i) * ldwo * 2 + 512 * c + ((dc ^ sw) << 4)),
+                                           (lptr_t)(myslot + slot * 8192 + i * 1024), 16, 0, 0);
+        }
+      };
+      dma_chunk(0, 0);
+      asm volatile("" ::: "memory");
+      dma_chunk(1, 1);
+      asm volatile("" ::: "memory");
+      bf16x8_t xb[NCW][4];
       const T* xrow = da + prow * ldda + half * 8 + 64 * wave;
-      const T* wrow0 = wo + (int64_t)(h * 64 + l31) * ldwo + half * 8 + 64 * wave;
-      const T* wrow1 = wrow0 + 32 * ldwo;
 #pragma unroll
       for (int c = 0; c < NCW; ++c)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          constexpr int dummy = 0; (void)dummy;
-          xb[c][kk] = *reinterpret_cast<const bf16x8_t*>(xrow + (256 * c + 16 * kk));
-          wa[0][c][kk] = *reinterpret_cast<const bf16x8_t*>(wrow0 + (256 * c + 16 * kk));
-          wa[1][c][kk] = *reinterpret_cast<const bf16x8_t*>(wrow1 + (256 * c + 16 * kk));
-        }
+        for (int kk = 0; kk < 4; ++kk) xb[c][kk] = *reinterpret_cast<const bf16x8_t*>(xrow + (256 * c + 16 * kk));
+      asm volatile("" ::: "memory");
+      constexpr int CHUNKS = NT * 32 * 8, ITERS = (CHUNKS + 255) / 256;
+      constexpr int NXQ = 4 * NCW;                 // the xb loads (qf was requested before the first DMA: older)
       f32x16_t dpart[2];
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpart[jt][r] = 0.f;
+      const int fsw = (l31 >> 1) & 7;
+      auto mfma_chunk = [&](int c, int slot) {
+        const char* base = myslot + slot * 8192 + l31 * 128;
 #pragma unroll
-        for (int c = 0; c < NCW; ++c)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) dpart[jt] = mfma16<T>(wa[jt][c][kk], xb[c][kk], dpart[jt]);
+        for (int kk = 0; kk < 4; ++kk) {
+          const int off = ((2 * kk + half) ^ fsw) << 4;
+          const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(base + off);
+          const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(base + 32 * 128 + off);
+          dpart[0] = mfma16<T>(a0, xb[c][kk], dpart[0]);
+          dpart[1] = mfma16<T>(a1, xb[c][kk], dpart[1]);
+        }
+      };
+      // younger than chunk 0: chunk 1 (8) + xb / qf
+#ifdef RPO_FUSED_SAFE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NXQ) : "memory");
+#endif
+      mfma_chunk(0, 0);
+      if constexpr (NCW == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slot 0 has been read
+        dma_chunk(2, 0);
+        asm volatile("" ::: "memory");
       }
-      // K / V rows are requested only now -- the 144 operand registers above are dead, the kernel runs two waves per
-      // SIMD on 256 registers -- and written to LDS once the partial tiles have been exchanged through it
-      constexpr int CHUNKS = NT * 32 * 8, ITERS = (CHUNKS + 255) / 256;
       uint4 ka[ITERS], va[ITERS];
-      asm volatile("" ::: "memory");
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {         // unconditional (clamped) loads: a branch per load serialises them
         const int id = tid + it * 256, key = min(id >> 3, N - 1), c = id & 7;
         ka[it] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * ldkv + c * 8);
         va[it] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ldkv + c * 8);
       }
-      float4* px = reinterpret_cast<float4*>(smem);                // [4 waves][8][64 lanes]
+#ifdef RPO_FUSED_SAFE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXQ + (NCW == 3 ? 8 : 0) + 2 * ITERS) : "memory");   // younger than chunk 1
+#endif
+      mfma_chunk(1, 1);
+      if constexpr (NCW == 3) {
+#ifdef RPO_FUSED_SAFE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * ITERS) : "memory");                            // younger than chunk 2
+#endif
+        mfma_chunk(2, 0);
+      }
+      RPO_STAMP(11);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float4* px = reinterpret_cast<float4*>(myslot);              // this wave's partial tiles: [8][64 lanes], in its own slot
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        px[(wave * 8 + i) * 64 + lane] = make_float4(dpart[i >> 2][4 * (i & 3)], dpart[i >> 2][4 * (i & 3) + 1],
-                                                     dpart[i >> 2][4 * (i & 3) + 2], dpart[i >> 2][4 * (i & 3) + 3]);
+        px[i * 64 + lane] = make_float4(dpart[i >> 2][4 * (i & 3)], dpart[i >> 2][4 * (i & 3) + 1],
+                                        dpart[i >> 2][4 * (i & 3) + 2], dpart[i >> 2][4 * (i & 3) + 3]);
       __syncthreads();
       float dfull[32];
+      const float4* pall = reinterpret_cast<const float4*>(smem);   // wave w's partials start at byte 16384 * w
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float4 a = px[i * 64 + lane], b = px[(8 + i) * 64 + lane], c = px[(16 + i) * 64 + lane],
-                     d = px[(24 + i) * 64 + lane];
+        const float4 a = pall[i * 64 + lane], b = pall[1024 + i * 64 + lane], c = pall[2048 + i * 64 + lane],
+                     d = pall[3072 + i * 64 + lane];
         dfull[4 * i] = (a.x + b.x) + (c.x + d.x); dfull[4 * i + 1] = (a.y + b.y) + (c.y + d.y);
         dfull[4 * i + 2] = (a.z + b.z) + (c.z + d.z); dfull[4 * i + 3] = (a.w + b.w) + (c.w + d.w);
       }
 #pragma unroll
       for (int ks2 = 0; ks2 < 4; ++ks2) dcd[ks2] = pack8<T>(dfull + 8 * ks2);
       __syncthreads();                             // the partials have been read: K / V may land on them
+      RPO_STAMP(12);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const int id = tid + it * 256, key = id >> 3, c = id & 7;
@@ -536,6 +586,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
       stage_rows_f32<NT, 256>(reinterpret_cast<float*>(vs), vb, ldkv, N, tid);
     }
     __syncthreads();
+    RPO_STAMP(13);
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
     // phase 1 (every wave, 4 MFMAs per tile): row max and sum of the scores, online -- nothing else is kept,
@@ -550,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    RPO_STAMP(14);
     // phase 2: this wave's key tiles t = wave, wave+4, ...
     f32x16_t u[2], w[2];
 #pragma unroll
@@ -600,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
       }
     }
     delta += __shfl_xor(delta, 32, 64);
+    RPO_STAMP(15);
     __syncthreads();                               // everybody is done with the staged K / V
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -627,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* __restrict__ 
                       scale * (us.z - dl * ws.z), scale * (us.w - dl * ws.w));
       }
     }
+    RPO_STAMP(16);
   }
 }
 
@@ -662,7 +716,7 @@ int launch_bwd_proj(const void* qr, int64_t ldq, const void* k, const void* v, i
                     float scale, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT, NCW>;
-  constexpr int bytes = AL<T, NT>::BWD_BYTES;
+  constexpr int bytes = AL<T, NT>::BWD_BYTES > 65536 ? AL<T, NT>::BWD_BYTES : 65536;   // 4 waves x 2 weight slots of 8 KiB
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(dx), lddx,
