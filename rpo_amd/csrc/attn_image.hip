@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
                                                        float scale, const T* wo = nullptr, int64_t ldwo = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
+  constexpr int stat_off = NCW > 0 && L::BWD_BYTES < 65536 ? 65536 : L::BWD_BYTES;   // launchers allocate stat_off + 2048
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -589,17 +590,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
     RPO_STAMP(13);
     int l31v = l31;
     asm volatile("" : "+v"(l31v));
-    // phase 1 (every wave, 4 MFMAs per tile): row max and sum of the scores, online -- nothing else is kept,
-    // which keeps the kernel at two workgroups per CU (all 384 (image, head) workgroups resident at once)
+    // phase 1 (4 MFMAs per tile): row max and sum of the scores, online -- nothing else is kept, which keeps the
+    // kernel at two workgroups per CU (all 384 (image, head) workgroups resident at once).  Each wave takes the key
+    // tiles it will own in phase 2 (t = wave, wave + 4, ...); the four (max, sum) pairs are merged through 2 KB of LDS
+    // behind the staging area (every wave scanning all tiles cost 6 k cycles of a 28 k-cycle kernel).
     float m = -INFINITY, l = 0.f;
 #pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
+    for (int t = wave; t < NT; t += 4) {
       f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
       const float mn = fmaxf(m, mask_and_max(sc, t, N, half));
-      l = l * exp_scalar<T>(m - mn, scale) + exp_tile<T>(sc, mn, scale);
-      m = mn;
+      if (mn > -INFINITY) {                          // a wave whose tiles hold no key at all keeps (-inf, 0)
+        l = l * exp_scalar<T>(m - mn, scale) + exp_tile<T>(sc, mn, scale);
+        m = mn;
+      }
     }
     l += __shfl_xor(l, 32, 64);
+    float2* rowstat = reinterpret_cast<float2*>(smem + stat_off);   // [4 waves][64 lanes]
+    rowstat[wave * 64 + lane] = make_float2(m, l);
+    __syncthreads();
+    {
+      const float2 s0 = rowstat[lane], s1 = rowstat[64 + lane], s2 = rowstat[128 + lane], s3 = rowstat[192 + lane];
+      m = fmaxf(fmaxf(s0.x, s1.x), fmaxf(s2.x, s3.x));              // tile 0 always holds keys: finite
+      l = (s0.y * exp_scalar<T>(s0.x - m, scale) + s1.y * exp_scalar<T>(s1.x - m, scale)) +
+          (s2.y * exp_scalar<T>(s2.x - m, scale) + s3.y * exp_scalar<T>(s3.x - m, scale));
+    }
     const float inv = 1.0f / l;
     RPO_STAMP(14);
     // phase 2: this wave's key tiles t = wave, wave+4, ...
@@ -702,7 +716,7 @@ int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_
                int64_t ldda, void* dq, int64_t lddq, int B, int H, int N, int Kp, float scale, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT>;
-  constexpr int bytes = AL<T, NT>::BWD_BYTES;
+  constexpr int bytes = AL<T, NT>::BWD_BYTES + 2048;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
@@ -716,7 +730,7 @@ int launch_bwd_proj(const void* qr, int64_t ldq, const void* k, const void* v, i
                     float scale, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT, NCW>;
-  constexpr int bytes = AL<T, NT>::BWD_BYTES > 65536 ? AL<T, NT>::BWD_BYTES : 65536;   // 4 waves x 2 weight slots of 8 KiB
+  constexpr int bytes = (AL<T, NT>::BWD_BYTES > 65536 ? AL<T, NT>::BWD_BYTES : 65536) + 2048;   // 4 waves x 2 weight slots of 8 KiB + row statistics
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(dx), lddx,
