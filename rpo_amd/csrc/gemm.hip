@@ -154,7 +154,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Workgroup id -> tile origin.  XCD-aware bijective remap (guide T1): XCD x = bid % 8 gets a contiguous run of
 // tiles; grouped order: consecutive ids sweep GM m-tiles of one n-tile, then the next n-tile, so the workgroups
 // resident on one XCD form a compact super-tile whose A and W panels fit its 4 MiB L2.
-template <int BM, int BN>
+#ifndef RPO_GM
+#define RPO_GM 8
+#endif
+template <int BM, int BN, int GM = RPO_GM>
 __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
   const int tiles_n = (p.N + BN - 1) / BN;      // BM, BN are powers of two or constants: shifts / mul-shift
   int wg;
@@ -163,10 +166,6 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }
-#ifndef RPO_GM
-#define RPO_GM 8
-#endif
-  constexpr int GM = RPO_GM;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_group = GM * tiles_n;
   // these divisions sit in front of the first DMA of every workgroup: a float reciprocal + one correction step
