@@ -312,7 +312,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   using L = AL<T, NT>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  // Block bid runs on XCD bid % 8: every XCD takes a contiguous run of (image, head) pairs, i.e. whole images -- the
+  // images whose rows the out-proj / c_fc / c_proj kernels around this one handle on the same XCD (row units).
+#ifdef RPO_ATTN_PLAIN_ORDER
+  const int wgid = blockIdx.x;
+#else
+  const int wgid = [&] {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  }();
+#endif
+  const int b = wgid / H, h = wgid % H;
   const T* kb = k + (int64_t)b * N * ld + h * 64;
   const T* vb = v + (int64_t)b * N * ld + h * 64;
   char* ks = smem;
@@ -443,7 +454,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  // Block bid runs on XCD bid % 8: every XCD takes a contiguous run of (image, head) pairs, i.e. whole images -- the
+  // images whose rows the out-proj / c_fc / c_proj kernels around this one handle on the same XCD (row units).
+#ifdef RPO_ATTN_PLAIN_ORDER
+  const int wgid = blockIdx.x;
+#else
+  const int wgid = [&] {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  }();
+#endif
+  const int b = wgid / H, h = wgid % H;
   const T* kb = k + (int64_t)b * N * ldkv + h * 64;
   const T* vb = v + (int64_t)b * N * ldkv + h * 64;
   char* ks = smem;
