@@ -13,6 +13,7 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("out_proj", 7072, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
     ("c_proj", 7072, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
+    ("last_kv", 6304, 1536, 768, EPI_BIAS, torch.bfloat16, 1),           # K / V of the frozen rows in the last image block
     ("c_fc_a", 5376, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),      # one full round of 256x256 tiles
     ("c_fc_b", 1696, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),      # the rest of c_fc's rows
     ("bwd_du", 768, 3072, 768, EPI_QGELU_BWD, torch.bfloat16, 1),
