@@ -864,7 +864,10 @@ int launch(const GemmParams& p, hipStream_t s) {
       const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
       if (g_ok && (p.force_cfg == 10 || (big_shape && !fills))) return launch_w4g<TOut, EPI>(p, s);
     }
-    if (w4_ok && (p.force_cfg == 8 || wants_big)) return launch_w4<TOut, EPI>(p, s);
+    // a single round that fills at least 55 % of the CUs still favours the one-wave-per-SIMD kernel (K / V projection of
+    // the frozen rows in the last image block, 6304 x 1536 x 768 = 150 tiles: 22.1 vs 25.6 us ping-pong, 28.6 us 128x128)
+    const bool one_round_ok = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536 && rounds == 1 && tiles * 100 >= 256 * 55;
+    if (w4_ok && (p.force_cfg == 8 || wants_big || one_round_ok)) return launch_w4<TOut, EPI>(p, s);
     if (ok && (p.force_cfg == 7 || wants_big)) return launch_pp<TOut, EPI>(p, s);
     if (ok && p.force_cfg == 3) return launch_cfg<TIn, TOut, EPI, CfgBig>(p, s);
   }

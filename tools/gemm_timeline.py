@@ -17,22 +17,10 @@ lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
-for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), 
-                                     ("c_proj_tall", 7072, 768, 3072, EPI_NONE, torch.float32, 6), ("one_wg_mid", 128, 128, 3072, EPI_NONE, torch.float32, 2),
-                                     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 3),
-                                     ("qkv_pingpong (stamps per 32-deep k-tile)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 7),
-                                     ("qkv_w4 (one wave per SIMD)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 8),
-                                     ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8),
-                                     ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
-                                     ("c_fc_w4g bias-only epilogue (store cost alone)", 7072, 3072, 768, EPI_BIAS, torch.bfloat16, 10)]:
-    if os.environ.get("TIMELINE_ONLY") and os.environ["TIMELINE_ONLY"] not in name:
-        continue
-    a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
-    out = torch.empty(M, N, dtype=odt, device=dev); bias = torch.randn(N, device=dev)
-    for _ in range(3):
-        buf.zero_()
-        ops.gemm_nt(a, w, out, epi, bias=bias if epi != EPI_NONE else None, tile_config=cfg)
-    torch.cuda.synchronize()
+FLUSH = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+
+
+def show(name, M, N, K, cfg):
     t = buf.view(8, 64).cpu()
     print(f"== {name} M={M} N={N} K={K}  (s_memtime ticks = 100 MHz? shown raw deltas)")
     for b in range(8):
@@ -40,7 +28,7 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
         if r[0] == 0: continue
         nk = int((r[2:52] != 0).sum())
         deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
-        if cfg in (8, 10):
+        if cfg in (8, 10, 11):
             nk32 = K // 32
             print(f" wg {b*97:5d}: start->loop {int(r[2]-r[0]):6d} | loop {int(r[60]-r[2]):6d} = {nk32} tiles x {int(r[60]-r[2])//nk32} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}")
             continue
@@ -51,3 +39,29 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
                   f" || per tile, group 0: load {g(0)} bar {g(1)} compute {g(2)} bar {g(3)}; group 1: load {g(4)} bar {g(5)} compute {g(6)} bar {g(7)}")
             continue
         print(f" wg {b*97:5d}: start->tile0 {int(r[2]-r[0]):6d} | per-k-tile {deltas} | last-tile->epi {int(r[60]-r[2+nk-1]):6d} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])} || wave0 per-iter: vmcnt-wait {int(r[53])//max(nk,1)} barrier {int(r[54])//max(nk,1)} body(issue) {int(r[55])//max(nk,1)}")
+
+
+for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, torch.float32, 2), 
+                                     ("c_proj_tall", 7072, 768, 3072, EPI_NONE, torch.float32, 6), ("one_wg_mid", 128, 128, 3072, EPI_NONE, torch.float32, 2),
+                                     ("c_fc", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 0), ("qkv_big", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 3),
+                                     ("qkv_pingpong (stamps per 32-deep k-tile)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 7),
+                                     ("qkv_w4 (one wave per SIMD)", 7072, 2304, 768, EPI_BIAS, torch.bfloat16, 8),
+                                     ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8),
+                                     ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
+                                     ("c_fc_w4g bias-only epilogue (store cost alone)", 7072, 3072, 768, EPI_BIAS, torch.bfloat16, 10),
+                                     ("c_proj_w4k (224x96, waves split k)", 7072, 768, 3072, EPI_BIAS_RESID, torch.float32, 11),
+                                     ("out_proj_w4k (224x96, waves split k)", 7072, 768, 768, EPI_BIAS_RESID, torch.float32, 11)]:
+    if os.environ.get("TIMELINE_ONLY") and os.environ["TIMELINE_ONLY"] not in name:
+        continue
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=odt, device=dev); bias = torch.randn(N, device=dev)
+    resid = torch.randn(M, N, device=dev) if epi == EPI_BIAS_RESID else None
+    units = (197, 24, 6304) if M == 7072 else None
+    for cold in ((False, True) if cfg in (8, 10, 11) else (False,)):
+      for _ in range(3):
+        if cold: FLUSH.fill_(1)                      # 512 MB written in between: operands out of L2 / MALL
+        buf.zero_()
+        ops.gemm_nt(a, w, out, epi, bias=bias if epi != EPI_NONE else None, resid=resid, tile_config=cfg, row_units=units)
+      torch.cuda.synchronize()
+      show(name + (" -- operands COLD" if cold else ""), M, N, K, cfg)
+    continue
