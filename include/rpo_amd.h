@@ -92,15 +92,21 @@ typedef struct rpo_gemm_args {
                                     slice s writes its partial product to C + s * split_stride; the
                                     consumer (rpo_layernorm_bwd's dy_splits) adds the slabs in order    */
   int64_t split_stride;          /* elements between slabs (>= M * ldc)                            */
-  int32_t tile_config;           /* 0 = choose by shape; for benchmarking: 2 = 128x128 tiles, 8 = 256x256 one wave per SIMD, 3 = 256x256 (bf16
-                                    in/out, BIAS / BIAS_QGELU only, else falls through), 5 = 64x64, 6 = 64x128,
-                                    7 = 256x256 ping-pong schedule (same conditions as 3; what 0 picks there) */
+  int32_t tile_config;           /* 0 = choose by shape.  For benchmarking / tests (a config whose conditions do not hold falls
+                                    through to the shape heuristic unless noted): 2 = 128x128 tiles, 5 = 64x64, 6 = 64x128,
+                                    9 = 128x128 with 4 waves; 16-bit in / out with a BIAS-type or LN epilogue: 3 = 256x256
+                                    lock-step, 7 = 256x256 ping-pong, 8 = 256x256 one wave per SIMD (what 0 picks when the
+                                    tiles fill a round of the CUs), 10 = 224x384 one round (N % 384 == 0, 208..256 tiles;
+                                    what 0 picks for c_fc at 32 images); BIAS_RESID, 16-bit in, fp32 out: 11 = 224x96 one
+                                    round with the waves splitting k (needs the row-unit hint below; RPO_E_SHAPE if it
+                                    does not apply).  Configs 2 / 3 / 5 / 6 / 7 / 8 / 9 / 10 give bit-identical results;
+                                    11 sums k in four parts and differs in the last bits                              */
   /* LayerNorm fold (all optional, 0 / NULL = off) */
   void* out2; int64_t ldout2;    /* BIAS_RESID: also store C in the act dtype (in_dtype) here: the A operand of the
                                     GEMM that consumes LN(C)                                        */
-  float* ln_stats;               /* BIAS_RESID: OUT, [M][N/64][2] fp32: (mean, sum of squared deviations) of every
-                                    64-column group of the row of C just written (N % 64 == 0).
-                                    LN_BIAS*: IN, the same array for the rows of A (groups = K / 64)  */
+  float* ln_stats;               /* BIAS_RESID: OUT, [M][N/g][2] fp32: (mean, sum of squared deviations) of every
+                                    g-column group of the row of C just written, g = ln_group (64 or 96).
+                                    LN_BIAS*: IN, the same array for the rows of A (groups = K / g <= 16) */
   const float* ln_colsum;        /* LN_BIAS*: s[n], fp32 [N]                                         */
   float ln_eps;                  /* LN_BIAS*: epsilon of the folded LayerNorm                        */
   /* Optional tiling hint (results do not depend on it): the rows of A / C are two segments, [0, seg1_row0) and
