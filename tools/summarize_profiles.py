@@ -25,6 +25,14 @@ lines = ["# PMC counters per launch (mean over launches) of the four forward GEM
          "# from separate `rocprofv3 --kernel-trace --pmc <set>` passes over `tools/bench_gemm.py --only <shape>`.\n"
          "# FETCH_SIZE / WRITE_SIZE are in KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x.\n"
          "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs) = MFMA-pipe utilisation.\n"]
+kernel_us = {}
+for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
+    f = glob.glob(os.path.join(raw, f"pmc_{shape}_SQ_VALU_MFMA_BUSY_CYCLES", "**", "*kernel_trace.csv"), recursive=True)
+    if f:
+        d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f[0]))
+                   if "gemm_w4" in r["Kernel_Name"])
+        if d:
+            kernel_us[shape] = d[len(d) // 2]
 for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
     lines.append(f"\n## {SH[shape]}\n")
     vals = {}
@@ -44,6 +52,22 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
         lines.append(f"{k:32s} {vals[k]:.5g}\n")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
         lines.append(f"{'-> MFMA pipe utilisation':32s} {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (vals['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
+    # One-wave-per-SIMD kernels: SQ_WAVE_CYCLES counts in units of 4 shader cycles, summed over the waves; with one wave
+    # per SIMD, (SQ_WAVE_CYCLES * 4 / waves) is the lifetime of a workgroup in SHADER cycles (it matches the s_memtime
+    # total of rNN_gemm_timeline.txt), which is the right denominator for MFMA busy cycles per SIMD.  GRBM_GUI_ACTIVE
+    # ticks at ~2.5 GHz whatever the shader clock is (the chip runs these kernels at ~1.6-1.8 GHz), so the ratio above
+    # under-states the time the pipes are busy.
+    waves = {"qkv": 252 * 4, "c_fc": 256 * 4, "c_proj": 256 * 4, "out_proj": 256 * 4}[shape]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "SQ_WAVE_CYCLES" in vals:
+        life = vals["SQ_WAVE_CYCLES"] * 4 / waves
+        busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / waves
+        lines.append(f"{'-> MFMA busy cycles per SIMD':32s} {busy:.0f}\n")
+        lines.append(f"{'-> wave lifetime, shader cycles':32s} {life:.0f}\n")
+        lines.append(f"{'-> MFMA busy / wave lifetime':32s} {busy / life:.3f}\n")
+        dur = kernel_us.get(shape)
+        if dur:
+            lines.append(f"{'-> kernel duration under PMC':32s} {dur:.1f} us  (=> GRBM_GUI_ACTIVE at {vals.get('GRBM_GUI_ACTIVE', 0) / 8 / dur / 1e3:.2f} GHz, "
+                         f"shader clock >= {life / dur / 1e3:.2f} GHz)\n")
     if "TCC_HIT_sum" in vals:
         lines.append(f"{'-> L2 hit rate':32s} {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.3f}\n")
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
