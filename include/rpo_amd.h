@@ -119,6 +119,10 @@ typedef struct rpo_gemm_args {
      image tower's out-proj and c_proj); a producer that cannot write the requested layout returns RPO_E_SHAPE, and the
      consuming LN_BIAS* GEMM must be given the same value. */
   int32_t ln_group;
+  /* What aux holds.  RPO_F32 (0, default): the fp32 pre-activation u -- *_QGELU epilogues write it, QGELU_BWD evaluates
+     quickgelu'(u).  in_dtype (16-bit modes only): d quickgelu / du itself in the act dtype ([rows, ldaux] of that type) --
+     *_QGELU epilogues write it, QGELU_BWD multiplies by it: half the bytes, no transcendental in the backward. */
+  int32_t aux_dtype;
 } rpo_gemm_args;
 
 int rpo_version(void);

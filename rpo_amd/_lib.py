@@ -49,6 +49,7 @@ class GemmArgs(C.Structure):
         ("ln_eps", c_f32),
         ("seg_rows0", c_i32), ("seg_rows1", c_i32), ("seg1_row0", c_i32),
         ("ln_group", c_i32),
+        ("aux_dtype", c_i32),
     ]
 
 

@@ -46,6 +46,7 @@ struct GemmParams {
   const float* bias;
   const float* resid; int64_t ldr;
   float* aux; int64_t ldaux; int aux_row0;
+  int aux_mode;                             // 0: aux holds the fp32 pre-activation u; 1: d quickgelu / du in the act dtype
   int skip_row0, skip_col0, group;
   int split_k; int64_t split_stride;   // elements of C between slabs
   int force_cfg;                       // 0 = heuristic; 2/3/5/6 force a tile shape (benchmarking)
@@ -184,6 +185,39 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
   m0 = tile_m * BM; n0 = tile_n * BN;
 }
 
+// The saved operand of the QuickGELU backward (rpo_gemm_args.aux / aux_dtype): either the fp32 pre-activation u (the
+// backward evaluates the derivative) or, in the 16-bit modes, the derivative itself in the act dtype -- half the bytes
+// of the forward's store (the c_fc kernel ended 4.5 us later with the fp32 store than without any), and no
+// transcendental in the backward epilogue.  `off` is in elements of the respective type.
+template <typename TA>
+__device__ __forceinline__ float4 aux_load4(const GemmParams& p, int64_t off) {
+  if constexpr (sizeof(TA) == 2) {
+    if (p.aux_mode) {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const TA*>(p.aux) + off);
+      return make_float4(unpack1<TA>((uint16_t)(u.x & 0xffffu)), unpack1<TA>((uint16_t)(u.x >> 16)),
+                         unpack1<TA>((uint16_t)(u.y & 0xffffu)), unpack1<TA>((uint16_t)(u.y >> 16)));
+    }
+  }
+  return *reinterpret_cast<const float4*>(p.aux + off);
+}
+// what the backward multiplies by, given what aux_load4 returned
+__device__ __forceinline__ float4 aux_to_grad(const GemmParams& p, const float4 a) {
+  if (p.aux_mode) return a;
+  return make_float4(quick_gelu_grad(a.x), quick_gelu_grad(a.y), quick_gelu_grad(a.z), quick_gelu_grad(a.w));
+}
+// forward side: u = the pre-activation of four consecutive columns
+template <typename TA>
+__device__ __forceinline__ void aux_store4(const GemmParams& p, int64_t off, const float4 u) {
+  if constexpr (sizeof(TA) == 2) {
+    if (p.aux_mode) {
+      *reinterpret_cast<uint2*>(reinterpret_cast<TA*>(p.aux) + off) =
+          make_uint2(pack2<TA>(quick_gelu_grad(u.x), quick_gelu_grad(u.y)), pack2<TA>(quick_gelu_grad(u.z), quick_gelu_grad(u.w)));
+      return;
+    }
+  }
+  *reinterpret_cast<float4*>(p.aux + off) = u;
+}
+
 // Epilogues that read a second [M, N] operand (residual / saved pre-activation) can fetch it BEFORE the main loop when
 // the row-major pass of a thread is a single group of 4 rows (64-row tiles: 4 float4 = 16 VGPRs): the HBM round trip
 // then overlaps the k-loop instead of sitting in the epilogue.
@@ -192,7 +226,7 @@ struct EpiPre {
   static constexpr int CPR = CF::BN / 4, RPP = CF::THREADS / CPR;
   static constexpr bool value = !CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_QGELU_BWD) && CF::BM / RPP == 4;
 };
-template <int EPI, typename CF>
+template <int EPI, typename CF, typename TA>
 __device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0, float4 (&pre)[4]) {
   constexpr int CPR = EpiPre<EPI, CF>::CPR, RPP = EpiPre<EPI, CF>::RPP;
   const int tid = threadIdx.x;
@@ -204,7 +238,7 @@ __device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0,
     pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.N && m < p.M) {
       if (EPI == RPO_EPI_BIAS_RESID) pre[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)m * p.ldr + n);
-      else pre[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)m * p.ldaux + n);
+      else pre[u] = aux_load4<TA>(p, (int64_t)m * p.ldaux + n);
     }
   }
 }
@@ -313,7 +347,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             if (IS_QG) {
               const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
               if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
-                *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+                aux_store4<TAct>(p, (int64_t)(m - p.aux_row0) * p.ldaux + n, v);
               v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
             }
             if constexpr (sizeof(TOut) == 2)
@@ -384,7 +418,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           } else if (EPI == RPO_EPI_BIAS_RESID) {
             if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.resid + (int64_t)mc * p.ldr + n);
           } else if (EPI == RPO_EPI_QGELU_BWD) {
-            if (ok[u]) ex[u] = *reinterpret_cast<const float4*>(p.aux + (int64_t)mc * p.ldaux + n);
+            if (ok[u]) ex[u] = aux_load4<TAct>(p, (int64_t)mc * p.ldaux + n);
           }
         }
   #pragma unroll
@@ -400,16 +434,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           }
           if (IS_QG) {
-            if (SAVE_U && ok[u] && m >= p.aux_row0)
-              *reinterpret_cast<float4*>(p.aux + (int64_t)(m - p.aux_row0) * p.ldaux + n) = v;
+            if (SAVE_U && ok[u] && m >= p.aux_row0) aux_store4<TAct>(p, (int64_t)(m - p.aux_row0) * p.ldaux + n, v);
             v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
           }
           if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
             v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
           }
           if (EPI == RPO_EPI_QGELU_BWD) {
-            v.x *= quick_gelu_grad(ex[u].x); v.y *= quick_gelu_grad(ex[u].y);
-            v.z *= quick_gelu_grad(ex[u].z); v.w *= quick_gelu_grad(ex[u].w);
+            const float4 gq = aux_to_grad(p, ex[u]);
+            v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
           }
           if (ok[u]) ActIO<TOut>::st4(cbase + orow[u] * p.ldc + n, v.x, v.y, v.z, v.w);
           if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TAct) == 2) {
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   }
   float4 pre[4];
   if constexpr (EpiPre<EPI, CF>::value) {
-    epi_preload<EPI, CF>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
+    epi_preload<EPI, CF, TIn>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
                                               // in-loop DMA, so the counted waits below stay valid (conservative)
   }
 
@@ -979,6 +1012,8 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.bias = a->bias; p.resid = a->resid; p.ldr = a->ldr;
   p.aux = static_cast<float*>(a->aux); p.ldaux = a->ldaux; p.aux_row0 = a->aux_row0;
+  if (a->aux_dtype != RPO_F32 && (a->aux == nullptr || a->aux_dtype != a->in_dtype || !in_bf16)) return RPO_E_DTYPE;
+  p.aux_mode = a->aux_dtype != RPO_F32 ? 1 : 0;
   p.skip_row0 = a->skip_row0; p.skip_col0 = a->skip_col0; p.group = a->group;
   p.split_k = a->split_k <= 1 ? 1 : a->split_k;
   p.split_stride = a->split_stride;

@@ -170,7 +170,10 @@ class Engine:
         self.qkv = [a(R, 3 * dv) for _ in range(Lv)]
         self.att = a(R, dv)
         self.g = a(R, 4 * dv)
-        self.u = [f32(Rp, 4 * dv) for _ in range(Lv)]
+        # saved for the QuickGELU backward, prompt rows only: fp32 pre-activations in the f32 mode, the derivative itself
+        # in the act dtype in the 16-bit modes (rpo_gemm_args.aux_dtype)
+        au = f32 if os.environ.get("RPO_AUX_F32") == "1" else a      # A/B switch: fp32 pre-activations in every mode
+        self.u = [au(Rp, 4 * dv) for _ in range(Lv)]
         self.y_post = a(Rp, dv)
         self.img_f = f32(Rp, e)
         # backward temporaries (prompt rows)
@@ -190,7 +193,7 @@ class Engine:
         self.qt = [a(Rt, dt) for _ in range(Lt)]
         self.att_t = a(Rt, dt)
         self.gt = a(Rt, 4 * dt)
-        self.ut = [f32(Rt, 4 * dt) for _ in range(Lt)]
+        self.ut = [au(Rt, 4 * dt) for _ in range(Lt)]
         self.y_final = a(Rt, dt)
         self.text_f = f32(Rt, e)
         self.d_text_f = f32(Rt, e)

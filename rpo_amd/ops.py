@@ -76,6 +76,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
     args.ln_group = ln_group
+    if aux is not None and aux.dtype != torch.float32:      # 16-bit aux: holds d quickgelu / du (include/rpo_amd.h)
+        args.aux_dtype = dtype_code(aux.dtype)
     if row_units is not None:               # (rows per unit in segment 0, rows per unit in segment 1, first row of segment 1)
         args.seg_rows0, args.seg_rows1, args.seg1_row0 = row_units
     if ln_stats is not None:

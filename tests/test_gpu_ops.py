@@ -90,6 +90,13 @@ def test_gemm_epilogues(mode, M, N, K):
     close(o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0), R.qgelu(pre), mode, "gemm qgelu")
     close(aux, pre[row0:], mode, "gemm qgelu saved u", tol=TOL["f32"] if mode == "f32" else 1e-4)
     close(o.gemm_nt(ad, wd, out, L.EPI_QGELU_BWD, aux=ud), acc * R.qgelu_grad(u.double()), mode, "gemm qgelu bwd")
+    if mode != "f32":
+        # 16-bit modes: aux may hold d quickgelu / du in the act dtype instead (rpo_gemm_args.aux_dtype)
+        aux16 = torch.full((M - row0, N), float("nan"), dtype=act, device=dev())
+        close(o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux16, aux_row0=row0), R.qgelu(pre), mode, "gemm qgelu (aux16)")
+        close(aux16, R.qgelu_grad(pre[row0:]), mode, "gemm qgelu saved derivative")
+        d16 = R.qgelu_grad(u.double()).float().to(dev(), act)
+        close(o.gemm_nt(ad, wd, out, L.EPI_QGELU_BWD, aux=d16), acc * d16.double().cpu(), mode, "gemm qgelu bwd (aux16)")
     # skipped rectangle must stay untouched, the rest must be computed
     out.fill_(7.0)
     sr, sc = 128, 128
@@ -275,6 +282,16 @@ def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
     close(res["units"][1], pre[row0:], mode, "row-unit tiles, saved u")
     for name in ("contiguous", "128x128", "bad hint", "auto"):
         assert torch.equal(res[name][0], res["units"][0]) and torch.equal(res[name][1], res["units"][1]), name
+    # the derivative form of the saved operand (16-bit aux): every tiling stores the same bits, close to float64
+    d_res = {}
+    for name, cfg, hint in (("units", 10, (n0, n1, seg1)), ("128x128", 2, None), ("64x64", 5, None)):
+        out = torch.empty((M, N), dtype=DT[mode], device=dev())
+        aux16 = torch.full((M - row0, N), float("nan"), dtype=DT[mode], device=dev())
+        o.gemm_nt(ad, wd, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux16, aux_row0=row0, tile_config=cfg, row_units=hint)
+        assert torch.equal(out, res["units"][0])
+        d_res[name] = aux16
+    close(d_res["units"], R.qgelu_grad(pre[row0:]), mode, "row-unit tiles, saved derivative")
+    assert torch.equal(d_res["128x128"], d_res["units"]) and torch.equal(d_res["64x64"], d_res["units"])
     for _ in range(10):
         out = torch.empty((M, N), dtype=DT[mode], device=dev())
         aux = torch.empty((M - row0, N), device=dev())
