@@ -895,7 +895,9 @@ int launch(const GemmParams& p, hipStream_t s) {
       W4GPlan gplan;
       const bool g_ok = w4_ok && w4g_plan(p, &gplan);
       const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
-      if (g_ok && (p.force_cfg == 10 || (big_shape && !fills))) return launch_w4g<TOut, EPI>(p, s);
+      // ... or whole rounds of row-unit tiles (64 / 128 images: 2 / 4 rounds; 256x256 tiles would need 2.6 / 5.3)
+      if (g_ok && (p.force_cfg == 10 || (big_shape && (!fills || (gplan.from_units && gplan.tiles_m * gplan.tiles_n % 256 == 0)))))
+        return launch_w4g<TOut, EPI>(p, s);
     }
     // a single round that fills at least 55 % of the CUs still favours the one-wave-per-SIMD kernel (K / V projection of
     // the frozen rows in the last image block, 6304 x 1536 x 768 = 150 tiles: 22.1 vs 25.6 us ping-pong, 28.6 us 128x128)
