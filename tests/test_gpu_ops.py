@@ -256,7 +256,8 @@ def test_gemm_one_round_224x384_bit_identical_and_race_screen(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-@pytest.mark.parametrize("n0,n1,units", [(197, 24, 32), (197, 4, 32), (197, 16, 32), (190, 34, 30), (224, 0, 28)])
+@pytest.mark.parametrize("n0,n1,units", [(197, 24, 32), (197, 4, 32), (197, 16, 32), (190, 34, 30), (224, 0, 28),
+                                         (197, 24, 64)])       # 64 units: two whole rounds of 256 tiles
 def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
     """rpo_gemm_args.seg_rows0 / seg_rows1 / seg1_row0 (include/rpo_amd.h): the 224x384 kernel then builds one tile
     from one unit's rows of BOTH row segments (an image's frozen rows + its prompt rows).  Output and saved
@@ -301,7 +302,7 @@ def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("n0,n1,units,K", [(197, 24, 32, 768), (197, 24, 32, 3072), (197, 4, 32, 256), (190, 34, 30, 512),
-                                           (224, 0, 28, 1024)])
+                                           (224, 0, 28, 1024), (197, 24, 64, 256)])   # 64 units: two rounds
 def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
     """The 224x96 kernel of the N = 768 residual GEMMs (tile_config 11; out-proj / c_proj of the image tower: one row
     unit x 96 columns per workgroup, the four waves split the contraction): C, the 16-bit copy and the 96-column row
