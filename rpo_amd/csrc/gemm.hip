@@ -893,7 +893,7 @@ int launch(const GemmParams& p, hipStream_t s) {
     // 224x384 tiles when they cover the output in exactly one round and 256x256 tiles do not (c_fc at B = 32)
     {
       W4GPlan gplan;
-      const bool g_ok = w4_ok && w4g_plan(p, &gplan);
+      const bool g_ok = w4_ok && w4g_plan(p, &gplan) != 0;
       const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
       // ... or whole rounds of row-unit tiles (64 / 128 images: 2 / 4 rounds; 256x256 tiles would need 2.6 / 5.3)
       if (g_ok && (p.force_cfg == 10 || (big_shape && (!fills || (gplan.from_units && gplan.tiles_m * gplan.tiles_n % 256 == 0)))))

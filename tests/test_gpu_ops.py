@@ -256,16 +256,17 @@ def test_gemm_one_round_224x384_bit_identical_and_race_screen(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-@pytest.mark.parametrize("n0,n1,units", [(197, 24, 32), (197, 4, 32), (197, 16, 32), (190, 34, 30), (224, 0, 28),
-                                         (197, 24, 64)])       # 64 units: two whole rounds of 256 tiles
-def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units):
+@pytest.mark.parametrize("n0,n1,units,N", [(197, 24, 32, 3072), (197, 4, 32, 3072), (197, 16, 32, 3072), (190, 34, 30, 3072),
+                                           (224, 0, 28, 3072), (197, 24, 64, 3072),      # 64 units: two rounds of 256 tiles
+                                           (257, 24, 16, 4096), (270, 18, 15, 4096)])    # ViT-L/14 rows: 288 x 256 tiles
+def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units, N):
     """rpo_gemm_args.seg_rows0 / seg_rows1 / seg1_row0 (include/rpo_amd.h): the 224x384 kernel then builds one tile
     from one unit's rows of BOTH row segments (an image's frozen rows + its prompt rows).  Output and saved
     pre-activations must be the bits of the contiguous tiling and of the 128x128 kernel; a hint that does not describe
     the matrix is ignored."""
     from rpo_amd import _lib as L
     o = ops()
-    K, N = 256, 3072
+    K = 256
     seg1 = n0 * units
     M = seg1 + n1 * units
     a, w, bias = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)

@@ -5,13 +5,15 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rpo_amd import ops, synth
-from rpo_amd.config import vit_b16
+from rpo_amd.config import vit_b16, vit_l14
 from rpo_amd.trainer import RPO
-cfg = vit_b16()
+LARGE = os.environ.get("MODEL") == "ViT-L/14"
+cfg = vit_l14() if LARGE else vit_b16()
+BATCH = 16 if LARGE else 32
 toks = synth.default_tokens(cfg)
 sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
-tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=32, num_batches=10**9)
-img = torch.randn(32, 3, 224, 224, device="cuda"); lab = torch.zeros(32, dtype=torch.int64, device="cuda")
+tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=BATCH, num_batches=10**9)
+img = torch.randn(BATCH, 3, cfg.image_size, cfg.image_size, device="cuda"); lab = torch.zeros(BATCH, dtype=torch.int64, device="cuda")
 for _ in range(3): tr.step_async(img, lab)
 torch.cuda.synchronize()
 p, g, b = (torch.zeros(256, device="cuda") for _ in range(3))
