@@ -863,8 +863,9 @@ int launch(const GemmParams& p, hipStream_t s) {
   if constexpr (EPI == RPO_EPI_BIAS_RESID && sizeof(TIn) == 2 && sizeof(TOut) == 4) {
     W4KPlan kplan;
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
-    const bool k_ok = p.split_k == 1 && fits32 && w4k_plan(p, &kplan) && aligned16(p.C) && p.ldc % 4 == 0 &&
-                      (p.ln_stats == nullptr || p.ln_group == CfgW4K::BN);
+    const int kgrp = w4k_plan(p, &kplan);                           // 0, or the geometry's statistics group (96 / 64)
+    const bool k_ok = p.split_k == 1 && fits32 && kgrp != 0 && aligned16(p.C) && p.ldc % 4 == 0 &&
+                      (p.ln_stats == nullptr || p.ln_group == kgrp);
     if (k_ok && (p.force_cfg == 11 || p.force_cfg == 0)) return launch_w4k<TIn>(p, s);
     if (p.force_cfg == 11 || (p.ln_stats != nullptr && p.ln_group != LN_GROUP)) return RPO_E_SHAPE;
   }
@@ -970,7 +971,8 @@ extern "C" int rpo_gemm_stats_group(const rpo_gemm_args* a) {
   p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
   W4KPlan q;
   const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
-  return fits32 && w4k_plan(p, &q) ? CfgW4K::BN : LN_GROUP;
+  const int kgrp = fits32 ? w4k_plan(p, &q) : 0;
+  return kgrp != 0 ? kgrp : LN_GROUP;
 }
 
 extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {

@@ -375,6 +375,51 @@ def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("n0,n1,units,K", [(257, 24, 16, 1024), (257, 24, 16, 4096), (270, 18, 15, 768), (257, 4, 16, 256)])
+def test_gemm_one_round_288x64_split_k(mode, n0, n1, units, K):
+    """The 288x64 geometry of the split-k kernel (ViT-L/14: 257 + K rows per image, 1024 = 16 x 64 columns; LDS ring of 3,
+    unrolled body of 6 iterations entered at position 5 (K = 1024, 4096, 256) or 3 (K = 768)): C, the 16-bit copy and
+    the 64-column row statistics against float64 and against the 64x128 tiles; deterministic over 25 launches."""
+    from rpo_amd import _lib as L
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    N = 1024
+    seg1 = n0 * units
+    M = seg1 + n1 * units
+    hint = (n0, n1, seg1)
+    dt = DT[mode]
+    a, w, bias = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    resid = rnd((M, N), 4, 2.0) + 0.4
+    ad, wd, bd, rd = a.to(dev(), dt), w.to(dev(), dt), bias.to(dev()), resid.to(dev())
+
+    def run(cfg, units_hint=hint):
+        c = torch.full((M, N), float("nan"), device=dev())
+        c2 = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        st = torch.full((M, N // 64, 2), float("nan"), device=dev())
+        o.gemm_nt(ad, wd, c, L.EPI_BIAS_RESID, bias=bd, resid=rd, out2=c2, ln_stats=st, tile_config=cfg, row_units=units_hint)
+        return c, c2, st
+
+    assert o.gemm_stats_group(M, N, K, dt, hint) == 64
+    c, c2, st = run(11)
+    ref = q(a, mode) @ q(w, mode).t() + bias.double() + resid.double()
+    close(c, ref, "f32", "288x64 split-k C", tol=1e-4)
+    assert torch.equal(c2.cpu(), c.cpu().to(dt)), "out2 must be the RNE act-dtype copy of C"
+    grp = c.double().cpu().reshape(M, N // 64, 64)
+    ref_st = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1)
+    close(st, ref_st, "f32", "64-column partial row statistics", tol=2e-5)
+    c0, c20, st0 = run(0)                          # the heuristic picks the same kernel
+    assert torch.equal(c0, c) and torch.equal(c20, c2) and torch.equal(st0, st)
+    for _ in range(25):
+        cr, c2r, str_ = run(11)
+        assert torch.equal(cr, c) and torch.equal(c2r, c2) and torch.equal(str_, st), "not deterministic: LDS race"
+    cg, _, stg = run(6, units_hint=None)           # generic 64x128 tiles
+    close(cg, c.double().cpu(), "f32", "64x128 tiles vs 288x64", tol=2e-5)
+    close(stg, st.double().cpu(), "f32", "statistics, 64x128 tiles vs 288x64", tol=2e-5)
+    with pytest.raises(RPOLibraryError):
+        run(11, units_hint=None)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("M,d,N", [(300, 768, 3072), (4200, 768, 2304), (1000, 1024, 4096), (7072, 768, 3072)])
 def test_gemm_layernorm_fold(mode, M, d, N):
     """LayerNorm folded into the GEMM around it (include/rpo_amd.h RPO_EPI_LN_*): the producer (BIAS_RESID) leaves the
