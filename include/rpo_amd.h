@@ -96,9 +96,10 @@ typedef struct rpo_gemm_args {
                                     through to the shape heuristic unless noted): 2 = 128x128 tiles, 5 = 64x64, 6 = 64x128,
                                     9 = 128x128 with 4 waves; 16-bit in / out with a BIAS-type or LN epilogue: 3 = 256x256
                                     lock-step, 7 = 256x256 ping-pong, 8 = 256x256 one wave per SIMD (what 0 picks when the
-                                    tiles fill a round of the CUs), 10 = 224x384 one round (N % 384 == 0, 208..256 tiles;
-                                    what 0 picks for c_fc at 32 images); BIAS_RESID, 16-bit in, fp32 out: 11 = 224x96 one
-                                    round with the waves splitting k (needs the row-unit hint below; RPO_E_SHAPE if it
+                                    tiles fill a round of the CUs), 10 = 224x384 (N % 384 == 0) or 288x256 (N % 256 == 0)
+                                    tiles in whole rounds of the CUs (what 0 picks for c_fc at 32 / 64 / 128 images of
+                                    ViT-B/16, 16 of ViT-L/14); BIAS_RESID, 16-bit in, fp32 out: 11 = 224x96 or 288x64
+                                    tiles with the waves splitting k (needs the row-unit hint below; RPO_E_SHAPE if it
                                     does not apply).  Configs 2 / 3 / 5 / 6 / 7 / 8 / 9 / 10 give bit-identical results;
                                     11 sums k in four parts and differs in the last bits                              */
   /* LayerNorm fold (all optional, 0 / NULL = off) */
@@ -116,8 +117,9 @@ typedef struct rpo_gemm_args {
   int32_t seg_rows0, seg_rows1, seg1_row0;
   /* Columns per partial row statistic in ln_stats: 0 or 64 (default), or 96.  96 is what the one-round 224x96 kernel
      writes (BIAS_RESID with a row-unit hint, N % 96 == 0, K % 256 == 0: tile_config 11 / the heuristic's choice for the
-     image tower's out-proj and c_proj); a producer that cannot write the requested layout returns RPO_E_SHAPE, and the
-     consuming LN_BIAS* GEMM must be given the same value. */
+     image tower's out-proj and c_proj of ViT-B/16; its 288x64 geometry for ViT-L/14 writes 64); a producer that cannot
+     write the requested layout returns RPO_E_SHAPE, and the consuming LN_BIAS* GEMM must be given the same value.
+     rpo_gemm_stats_group() tells which. */
   int32_t ln_group;
   /* What aux holds.  RPO_F32 (0, default): the fp32 pre-activation u -- *_QGELU epilogues write it, QGELU_BWD evaluates
      quickgelu'(u).  in_dtype (16-bit modes only): d quickgelu / du itself in the act dtype ([rows, ldaux] of that type) --
