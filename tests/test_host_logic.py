@@ -6,6 +6,7 @@ import ctypes
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -266,3 +267,14 @@ def test_prec_mapping():
     assert act_dtype_for_prec("fp16") is torch.float16 and act_dtype_for_prec("amp") is torch.float16
     with pytest.raises(ValueError):
         act_dtype_for_prec("int8")
+
+
+def test_generated_k_loops_are_what_the_generators_emit(tmp_path):
+    """rpo_amd/csrc/gemm_w4g_asm.inc / gemm_w4k_asm.inc are committed generator output (tools/gen_gemm_w4*.py): a hand edit
+    of either side without the other would silently change a schedule whose wait counts are derived, not written."""
+    import subprocess
+    for gen, inc in (("gen_gemm_w4g.py", "gemm_w4g_asm.inc"), ("gen_gemm_w4k.py", "gemm_w4k_asm.inc")):
+        out = tmp_path / inc
+        env = {k: v for k, v in os.environ.items() if not k.startswith("W4K_")}
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", gen), str(out)], env=env, stdout=subprocess.DEVNULL)
+        assert out.read_text() == open(os.path.join(ROOT, "rpo_amd", "csrc", inc)).read(), f"{inc} is stale: re-run tools/{gen}"

@@ -16,6 +16,7 @@ slot, s63 loop counter, s64 k byte offset of the tile being fetched, s71.. = i *
 operand each (%[offa0] ..): the rows of a tile may come from two row segments.
 """
 import os
+import sys
 
 
 class Geo:
@@ -149,6 +150,8 @@ def loop_lines():
 def main():
     global G
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rpo_amd", "csrc", "gemm_w4g_asm.inc")
+    if len(sys.argv) > 1:                            # tests regenerate into a scratch file and compare
+        out = sys.argv[1]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_w4g.py -- do not edit; the schedule and its wait counts are derived there.\n")
         f.write("// W4G_OP (the MFMA mnemonic) is bound where W4G_LOOP is expanded.\n")

@@ -23,6 +23,7 @@ Scratch: the four VGPRs below (two DMA offsets of the W pieces, the W / X read a
 offset of the tile being fetched, s71.. = 32 * i W rows.  The wait counts are derived from the issue order.
 """
 import os
+import sys
 from math import gcd
 
 
@@ -164,6 +165,8 @@ def loop_lines():
 def main():
     global G
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rpo_amd", "csrc", "gemm_w4k_asm.inc")
+    if len(sys.argv) > 1:                            # tests regenerate into a scratch file and compare
+        out = sys.argv[1]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_w4k.py -- do not edit; the schedule and its wait counts are derived there.\n")
         f.write("// W4K_OP (the MFMA mnemonic) is bound where W4K_LOOP is expanded.\n")
