@@ -170,6 +170,14 @@ int rpo_im2col_patches(const float* img, void* out, int out_dtype, int64_t ldo,
 int rpo_img_assemble(float* x, int64_t ldx, const float* cls, const float* pos0,
                      const float* img_prompt, int B, int N, int Kp, int d, void* stream);
 
+/* rpo_img_assemble + ln_pre + the first block's ln_1 in one launch (trainers/rpo.py:201-206, clip/model.py:189): per
+ * token row -- CLS + pos[0], the patch row already in x_pre, or the image's prompt row -- x0 = ln_pre(token) (fp32) and
+ * h = ln_1(x0) (h_dtype).  The CLS and prompt rows are also written to x_pre (the backward of ln_pre reads the prompt
+ * rows).  Same bits as the three separate launches.  d % 4 == 0, d <= 1024. */
+int rpo_img_embed_norm(float* x_pre, int64_t ldx, const float* cls, const float* pos0, const float* img_prompt,
+                       const float* g_pre, const float* b_pre, float* x0, int64_t ldx0, const float* g1, const float* b1,
+                       void* h, int64_t ldh, int h_dtype, int B, int N, int Kp, int d, float eps, void* stream);
+
 /* dst[g*rows + i, :] = src[i, :]  (text prompts written into every class, trainers/rpo.py:176-177) */
 int rpo_broadcast_rows(const float* src, float* dst, int64_t ld, int groups, int rows, int d, void* stream);
 

@@ -63,6 +63,80 @@ __global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_fwd_kernel(const float* __
   }
 }
 
+// Image-tower input in one launch (trainers/rpo.py:201-206 + the first ln_1, clip/model.py:189): per row, the token
+// (CLS + pos[0] | the patch row the patch GEMM wrote | the image's prompt row), ln_pre of it (-> x0, fp32) and ln_1 of
+// that (-> h, act dtype).  Replaces assemble + two LayerNorm launches; every value is formed by the expressions of
+// ln_fwd_kernel in the same order, so x0 and h carry the bits the three launches produce.
+template <typename TY, int NV>
+__global__ __launch_bounds__(64 * RPO_LN_RPB) void img_embed_norm_kernel(float* x_pre, int64_t ldx,
+    const float* __restrict__ cls, const float* __restrict__ pos0, const float* __restrict__ prompt,
+    const float* __restrict__ g_pre, const float* __restrict__ b_pre, float* x0, int64_t ldx0,
+    const float* __restrict__ g1, const float* __restrict__ b1, TY* h, int64_t ldh, int B, int N, int Kp, int d,
+    float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);
+  const int rows = B * (N + Kp);
+  if (row >= rows) return;
+  const int nv4 = d >> 2;
+  const bool is_prompt = row >= B * N;
+  const bool is_cls = !is_prompt && row % N == 0;
+  const float* src = is_prompt ? prompt + (int64_t)((row - B * N) % Kp) * d : (is_cls ? cls : x_pre + (int64_t)row * ldx);
+  float4 v[NV], ga[NV], ba[NV], gb[NV], bb[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv4) {
+      v[i] = *reinterpret_cast<const float4*>(src + 4 * c);
+      if (is_cls) {
+        const float4 p4 = *reinterpret_cast<const float4*>(pos0 + 4 * c);
+        v[i].x += p4.x; v[i].y += p4.y; v[i].z += p4.z; v[i].w += p4.w;
+      }
+      ga[i] = *reinterpret_cast<const float4*>(g_pre + 4 * c); ba[i] = *reinterpret_cast<const float4*>(b_pre + 4 * c);
+      gb[i] = *reinterpret_cast<const float4*>(g1 + 4 * c);    bb[i] = *reinterpret_cast<const float4*>(b1 + 4 * c);
+      if (is_cls || is_prompt) *reinterpret_cast<float4*>(x_pre + (int64_t)row * ldx + 4 * c) = v[i];   // the backward reads these rows
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  auto norm = [&](float4 (&g)[NV], float4 (&b)[NV], float ssum) {
+    const float mu = wave_sum(ssum) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float a = v[i].x - mu, b2 = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+        q += (a * a + b2 * b2) + (cc * cc + dd * dd);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    float sn = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        v[i] = make_float4((v[i].x - mu) * rstd * g[i].x + b[i].x, (v[i].y - mu) * rstd * g[i].y + b[i].y,
+                           (v[i].z - mu) * rstd * g[i].z + b[i].z, (v[i].w - mu) * rstd * g[i].w + b[i].w);
+        sn += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    return sn;
+  };
+  const float s1 = norm(ga, ba, s);                                   // ln_pre
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) *reinterpret_cast<float4*>(x0 + (int64_t)row * ldx0 + 4 * c) = v[i];
+  }
+  (void)norm(gb, bb, s1);                                             // ln_1 of the first block
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) ActIO<TY>::st4(h + (int64_t)row * ldh + 4 * c, v[i].x, v[i].y, v[i].z, v[i].w);
+  }
+}
+
 template <typename T> __device__ __forceinline__ float4 load4f(const T* p);
 template <> __device__ __forceinline__ float4 load4f<float>(const float* p) {
   return *reinterpret_cast<const float4*>(p);
@@ -244,5 +318,32 @@ extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, con
   }
 #undef RPO_LN_BWD
 #undef RPO_LN_BWD_
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_img_embed_norm(float* x_pre, int64_t ldx, const float* cls, const float* pos0, const float* img_prompt,
+                                  const float* g_pre, const float* b_pre, float* x0, int64_t ldx0, const float* g1,
+                                  const float* b1, void* h, int64_t ldh, int h_dtype, int B, int N, int Kp, int d,
+                                  float eps, void* stream) {
+  if (!x_pre || !cls || !pos0 || !g_pre || !b_pre || !x0 || !g1 || !b1 || !h || B <= 0 || N <= 0 || Kp < 0 || d <= 0 ||
+      (Kp > 0 && !img_prompt)) return RPO_E_BADARG;
+  if (d % 4 != 0 || d > 64 * 4 * 4) return RPO_E_SHAPE;
+  if (!aligned16(x_pre) || !aligned16(cls) || !aligned16(pos0) || (Kp > 0 && !aligned16(img_prompt)) || !aligned16(g_pre) ||
+      !aligned16(b_pre) || !aligned16(x0) || !aligned16(g1) || !aligned16(b1) || ldx % 4 != 0 || ldx0 % 4 != 0 ||
+      ldh % 4 != 0 || reinterpret_cast<uintptr_t>(h) % (h_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rows = B * (N + Kp);
+  const dim3 grid((rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
+  const int nv = (d / 4 + 63) / 64;
+#define RPO_IEN(TY, NV)                                                                                       \
+  hipLaunchKernelGGL((img_embed_norm_kernel<TY, NV>), grid, block, 0, s, x_pre, ldx, cls, pos0, img_prompt, g_pre, \
+                     b_pre, x0, ldx0, g1, b1, static_cast<TY*>(h), ldh, B, N, Kp, d, eps)
+#define RPO_IEN_NV(TY) do { if (nv <= 2) RPO_IEN(TY, 2); else if (nv == 3) RPO_IEN(TY, 3); else RPO_IEN(TY, 4); } while (0)
+  if (h_dtype == RPO_F32) RPO_IEN_NV(float);
+  else if (h_dtype == RPO_BF16) RPO_IEN_NV(bf16_t);
+  else if (h_dtype == RPO_F16) RPO_IEN_NV(f16_t);
+  else return RPO_E_DTYPE;
+#undef RPO_IEN_NV
+#undef RPO_IEN
   return rpo_launch_status();
 }

@@ -300,9 +300,10 @@ class Engine:
         ops.im2col_patches(image, self.im2col[:B * cfg.n_patches], cfg.patch)
         ops.gemm_nt(self.im2col[:B * cfg.n_patches], self.conv_w, x_pre, EPI_PATCH, resid=self.pos,
                     group=cfg.n_patches)                                               # rpo.py:198-202
-        ops.img_assemble(x_pre, self.cls, self.pos, self.img_prompt, B, N, K)          # rpo.py:201-204
-        ops.layernorm_fwd(x_pre, self.ln_pre[0], self.ln_pre[1], self.x[0][:R])        # rpo.py:206
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
+        # CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch
+        ops.img_embed_norm(x_pre, self.cls, self.pos, self.img_prompt, self.ln_pre[0], self.ln_pre[1], self.x[0][:R],
+                           self.vis[0].ln1_w, self.vis[0].ln1_b, h, B, N, K)
         fold = self.fold_ln
         # Row units of the whole-stream GEMMs: one image = N frozen + K prompt rows.  With them c_fc tiles by image
         # (saved pre-activations spread over all workgroups) and out-proj / c_proj run as one round of 224x96 tiles,
@@ -323,7 +324,7 @@ class Engine:
             # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
             # left by the previous block's c_proj; the GEMM epilogue applies the normalisation (RPO_EPI_LN_BIAS).
             folded_in = fold and l > 0
-            if not folded_in:
+            if not folded_in and l > 0:                   # (block 0: h was written with x[0] above)
                 ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
             w_in, b_in = (blk.w_in_ln, blk.b_in_ln) if folded_in else (blk.w_in, blk.b_in)
             epi_in = EPI_LN_BIAS if folded_in else EPI_BIAS

@@ -135,6 +135,16 @@ def im2col_patches(img: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Te
     return out
 
 
+def img_embed_norm(x_pre, cls, pos0, img_prompt, g_pre, b_pre, x0, g1, b1, h, B: int, N: int, Kp: int,
+                   eps: float = LN_EPS):
+    """img_assemble + ln_pre (-> x0) + the first block's ln_1 (-> h) in one launch."""
+    check(_lib.load().rpo_img_embed_norm(x_pre.data_ptr(), _ld(x_pre), cls.data_ptr(), pos0.data_ptr(), _p(img_prompt),
+                                         g_pre.data_ptr(), b_pre.data_ptr(), x0.data_ptr(), _ld(x0), g1.data_ptr(),
+                                         b1.data_ptr(), h.data_ptr(), _ld(h), dtype_code(h.dtype), B, N, Kp,
+                                         x_pre.shape[1], eps, _stream()), "rpo_img_embed_norm")
+    return h
+
+
 def img_assemble(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, img_prompt: torch.Tensor, B: int, N: int,
                  Kp: int) -> torch.Tensor:
     check(_lib.load().rpo_img_assemble(x.data_ptr(), _ld(x), cls.data_ptr(), pos.data_ptr(), img_prompt.data_ptr(),

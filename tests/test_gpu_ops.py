@@ -696,6 +696,42 @@ def test_head_fwd_bwd(B, C, K, e):
     close(logits, lg, "f32", "head logits (bad label)", tol=5e-6)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("B,N,Kp,d", [(3, 50, 7, 768), (2, 197, 24, 768), (1, 17, 1, 1024), (2, 10, 0, 512)])
+def test_img_embed_norm_equals_assemble_plus_two_layernorms(mode, B, N, Kp, d):
+    """rpo_img_embed_norm: CLS / prompt rows + ln_pre + the first ln_1 in one launch -- the bits of rpo_img_assemble ->
+    rpo_layernorm_fwd -> rpo_layernorm_fwd, and float64-close (trainers/rpo.py:201-206, clip/model.py:189)."""
+    o = ops()
+    R_ = B * (N + Kp)
+    x_pre = rnd((R_, d), 1, 2.0)
+    cls, pos0 = rnd((d,), 2), rnd((d,), 3)
+    prompt = rnd((max(Kp, 1), d), 4)
+    gp, bp, g1, b1 = rnd((d,), 5, 0.1) + 1.0, rnd((d,), 6, 0.1), rnd((d,), 7, 0.1) + 1.0, rnd((d,), 8, 0.1)
+    dv = lambda t: t.to(dev())
+    # the three launches
+    xa = dv(x_pre).clone()
+    o.img_assemble(xa, dv(cls), dv(pos0), dv(prompt), B, N, Kp)
+    x0a = torch.empty(R_, d, device=dev()); ha = torch.empty(R_, d, dtype=DT[mode], device=dev())
+    o.layernorm_fwd(xa, dv(gp), dv(bp), x0a)
+    o.layernorm_fwd(x0a, dv(g1), dv(b1), ha)
+    # one launch
+    xb = dv(x_pre).clone()
+    x0b = torch.full((R_, d), float("nan"), device=dev()); hb = torch.full((R_, d), float("nan"), dtype=DT[mode], device=dev())
+    o.img_embed_norm(xb, dv(cls), dv(pos0), dv(prompt) if Kp else None, dv(gp), dv(bp), x0b, dv(g1), dv(b1), hb, B, N, Kp)
+    assert torch.equal(xb, xa), "x_pre rows (CLS, prompts) differ from rpo_img_assemble"
+    assert torch.equal(x0b, x0a) and torch.equal(hb, ha), "fused launch differs from the three separate ones"
+    # float64
+    tok = x_pre.double().clone()
+    for b in range(B):
+        tok[b * N] = cls.double() + pos0.double()
+        if Kp:
+            tok[B * N + b * Kp:B * N + (b + 1) * Kp] = prompt.double()
+    ln = lambda t, g, b_: (t - t.mean(1, keepdim=True)) / (t.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * g.double() + b_.double()
+    y1 = ln(tok, gp, bp)
+    close(x0b, y1, "f32", "ln_pre of the assembled tokens", tol=2e-5)
+    close(hb, ln(y1, g1, b1), mode, "ln_1 of that")
+
+
 def test_sgd_broadcast_reduce_convert():
     o = ops()
     n = 30720
