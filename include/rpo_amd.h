@@ -242,6 +242,11 @@ int64_t rpo_head_workspace_floats(int B, int C, int K, int e);
 int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
                      float* logits, float* loss, float* d_img_f, float* d_text_f,
                      int B, int C, int K, int e, float* workspace, void* stream);
+/* The same, also leaving act-dtype copies (RPO_BF16 / RPO_F16, round to nearest even) of the two feature gradients for
+ * the dX GEMMs of the projections that follow (either may be NULL). */
+int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
+                         float* logits, float* loss, float* d_img_f, float* d_text_f, void* d_img_f_act,
+                         void* d_text_f_act, int act_dtype, int B, int C, int K, int e, float* workspace, void* stream);
 
 /* torch.optim.SGD (dampening 0, no nesterov) on n fp32 scalars (trainers/rpo.py:274,309):
  *   g' = grad_scale * g + wd * p;  buf = first ? g' : momentum * buf + g';  p -= lr * buf

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ nt, float* d_img_f, float* d_text_f,
                                                        int B, int C, int K, int e, const float* loss_b, float* loss,
                                                        const float* __restrict__ logits,
-                                                       const int64_t* __restrict__ label, float gmul) {
+                                                       const int64_t* __restrict__ label, float gmul,
+                                                       void* d_img_a, void* d_text_a, int act_dtype) {
   extern __shared__ __attribute__((aligned(16))) char head_smem[];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -271,7 +272,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int idx = threadIdx.x + 256 * v;
-    if (idx < e) df[(int64_t)row * e + idx] = (dh[v] - h[v] * dot) * inv;
+    if (idx < e) {
+      const float g = (dh[v] - h[v] * dot) * inv;
+      df[(int64_t)row * e + idx] = g;
+      // the act-dtype copy the dX GEMM of the projection reads (RNE, as rpo_convert would make it)
+      void* da = img ? d_img_a : d_text_a;
+      if (da != nullptr) {
+        if (act_dtype == RPO_BF16) reinterpret_cast<uint16_t*>(da)[(int64_t)row * e + idx] = (uint16_t)(pack2<bf16_t>(g, 0.f) & 0xffffu);
+        else reinterpret_cast<uint16_t*>(da)[(int64_t)row * e + idx] = (uint16_t)(pack2<f16_t>(g, 0.f) & 0xffffu);
+      }
+    }
   }
 }
 
@@ -412,7 +422,16 @@ extern "C" int64_t rpo_head_workspace_floats(int B, int C, int K, int e) {
 extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
                                 float* logits, float* loss, float* d_img_f, float* d_text_f, int B, int C, int K,
                                 int e, float* ws, void* stream) {
+  return rpo_head_fwd_bwd_act(img_f, text_f, label, scale_exp, logits, loss, d_img_f, d_text_f, nullptr, nullptr, RPO_F32,
+                              B, C, K, e, ws, stream);
+}
+
+extern "C" int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
+                                    float* logits, float* loss, float* d_img_f, float* d_text_f, void* d_img_act,
+                                    void* d_text_act, int act_dtype, int B, int C, int K, int e, float* ws,
+                                    void* stream) {
   if (!img_f || !text_f || !logits || !ws || B <= 0 || C <= 0 || K <= 0 || e <= 0) return RPO_E_BADARG;
+  if ((d_img_act || d_text_act) && act_dtype != RPO_BF16 && act_dtype != RPO_F16) return RPO_E_DTYPE;
   if (label && (!loss || !d_img_f || !d_text_f)) return RPO_E_BADARG;
   if (e > 1024) return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -433,13 +452,13 @@ extern "C" int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const i
   const int nmax = B > C ? B : C;
   if (C <= 128 && B <= 2048) {
     hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(B * K + C * K), dim3(256), (size_t)(nmax + 3 * B) * sizeof(float), s,
-                       dl, img_f, ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul);
+                       dl, img_f, ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul, d_img_act, d_text_act, act_dtype);
     return rpo_launch_status();
   }
   if ((size_t)nmax * sizeof(float) > 64 * 1024) return RPO_E_SHAPE;
   hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
   hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(B * K + C * K), dim3(256), (size_t)nmax * sizeof(float), s, dl, img_f,
-                     ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul);
+                     ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul, d_img_act, d_text_act, act_dtype);
   return rpo_launch_status();
 }
 

@@ -408,7 +408,7 @@ class Engine:
         if self.act == torch.float32:
             d_f = self.d_img_f[:Rp]
         else:
-            d_f = ops.convert(self.d_img_f[:Rp], self.d_img_f_a[:Rp])
+            d_f = self.d_img_f_a[:Rp]                  # written by the head's backward
         ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, :Rp], EPI_NONE)
         ops.layernorm_bwd(self.dy_v[0, :Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
@@ -436,7 +436,7 @@ class Engine:
         cfg = self.cfg
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
-        d_f = self.d_text_f if self.act == torch.float32 else ops.convert(self.d_text_f, self.d_text_f_a)
+        d_f = self.d_text_f if self.act == torch.float32 else self.d_text_f_a      # written by the head's backward
         ops.gemm_nt(d_f, self.text_proj, self.dy_t[0], EPI_NONE)
         ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
@@ -490,6 +490,13 @@ class Engine:
         ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(self.cfg.n_cls, K, e), None,
                          self.logit_scale_exp, self.logits[:B], None, None, None, self.head_ws)
 
+    def _head_act(self, B: int) -> dict:
+        """16-bit modes: the head's backward also leaves the act-dtype copies of the two feature gradients that the dX GEMMs
+        of the projections read (no convert launches at the head of the backward chains)."""
+        if self.act == torch.float32:
+            return {}
+        return dict(d_img_f_act=self.d_img_f_a[:B * self.cfg.K], d_text_f_act=self.d_text_f_a)
+
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
         """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in
         self.loss, self.logits, self.grads (= [g_text | g_img]).  Capturable in a HIP graph."""
@@ -505,7 +512,7 @@ class Engine:
         main.wait_stream(self.side)
         ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(n, K, e), label, self.logit_scale_exp,
                          self.logits[:B], self.loss, self.d_img_f[:B * K].view(B, K, e),
-                         self.d_text_f.view(n, K, e), self.head_ws)
+                         self.d_text_f.view(n, K, e), self.head_ws, **self._head_act(B))
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._text_backward()
@@ -516,7 +523,7 @@ class Engine:
         K, e, n = self.cfg.K, self.cfg.embed, self.cfg.n_cls
         ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(n, K, e), label, self.logit_scale_exp,
                          self.logits[:B], self.loss, self.d_img_f[:B * K].view(B, K, e),
-                         self.d_text_f.view(n, K, e), self.head_ws)
+                         self.d_text_f.view(n, K, e), self.head_ws, **self._head_act(B))
 
     def _check(self, image: torch.Tensor) -> int:
         cfg = self.cfg

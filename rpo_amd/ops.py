@@ -218,14 +218,19 @@ def head_workspace_floats(B: int, Cc: int, K: int, e: int) -> int:
     return int(_lib.load().rpo_head_workspace_floats(B, Cc, K, e))
 
 
-def head_fwd_bwd(img_f, text_f, label, scale_exp: float, logits, loss, d_img_f, d_text_f, ws):
+def head_fwd_bwd(img_f, text_f, label, scale_exp: float, logits, loss, d_img_f, d_text_f, ws,
+                 d_img_f_act=None, d_text_f_act=None):
+    """d_*_act: optional act-dtype copies of the two gradients (what the projections' dX GEMMs read)."""
     B, K, e = img_f.shape
     Cc = text_f.shape[0]
     assert img_f.is_contiguous() and text_f.is_contiguous() and logits.is_contiguous()
     assert label is None or label.dtype == torch.int64
-    check(_lib.load().rpo_head_fwd_bwd(img_f.data_ptr(), text_f.data_ptr(), _p(label), scale_exp,
-                                       logits.data_ptr(), _p(loss), _p(d_img_f), _p(d_text_f), B, Cc, K, e,
-                                       ws.data_ptr(), _stream()), "rpo_head_fwd_bwd")
+    act = d_img_f_act if d_img_f_act is not None else d_text_f_act
+    assert act is None or (act.is_contiguous() and (d_text_f_act is None or d_text_f_act.is_contiguous()))
+    check(_lib.load().rpo_head_fwd_bwd_act(img_f.data_ptr(), text_f.data_ptr(), _p(label), scale_exp,
+                                           logits.data_ptr(), _p(loss), _p(d_img_f), _p(d_text_f), _p(d_img_f_act),
+                                           _p(d_text_f_act), _lib.RPO_F32 if act is None else dtype_code(act.dtype),
+                                           B, Cc, K, e, ws.data_ptr(), _stream()), "rpo_head_fwd_bwd_act")
     return logits
 
 

@@ -686,6 +686,10 @@ def test_head_fwd_bwd(B, C, K, e):
     assert abs(loss.item() - ls.item()) <= 5e-6 * max(1.0, abs(ls.item()))
     close(d_i, di, "f32", "head d_img_f", tol=2e-5)
     close(d_t, dt, "f32", "head d_text_f", tol=2e-5)
+    for adt in (torch.bfloat16, torch.float16):     # act-dtype copies for the projections' dX GEMMs: RNE of the fp32 result
+        ia, ta = torch.empty(B, K, e, dtype=adt, device=dev()), torch.empty(C, K, e, dtype=adt, device=dev())
+        o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), lab.to(dev()), 100.0, logits, loss, d_i, d_t, ws, d_img_f_act=ia, d_text_f_act=ta)
+        assert torch.equal(ia, d_i.to(adt)) and torch.equal(ta, d_t.to(adt))
     logits.zero_()
     o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), None, 100.0, logits, None, None, None, ws)
     close(logits, lg, "f32", "head logits (eval)", tol=5e-6)
