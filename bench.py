@@ -323,8 +323,8 @@ def self_launch(n: int) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--K", type=int, default=24)
     ap.add_argument("--model", default="ViT-B/16", choices=["ViT-B/16", "ViT-L/14"])
