@@ -49,6 +49,8 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
                                      ("c_fc_w4 (one wave per SIMD, 2 rounds)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 8),
                                      ("c_fc_w4g (224x384, one round)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
                                      ("c_fc_w4g bias-only epilogue (store cost alone)", 7072, 3072, 768, EPI_BIAS, torch.bfloat16, 10),
+                                     ("c_fc_w4g + saved QuickGELU operand of the prompt rows (act dtype)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
+                                     ("c_fc_w4g + saved QuickGELU operand of the prompt rows (fp32)", 7072, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 10),
                                      ("c_proj_w4k (224x96, waves split k)", 7072, 768, 3072, EPI_BIAS_RESID, torch.float32, 11),
                                      ("out_proj_w4k (224x96, waves split k)", 7072, 768, 768, EPI_BIAS_RESID, torch.float32, 11)]:
     if os.environ.get("TIMELINE_ONLY") and os.environ["TIMELINE_ONLY"] not in name:
@@ -61,7 +63,11 @@ for name, M, N, K, epi, odt, cfg in [("c_proj_mid2", 7072, 768, 3072, EPI_NONE, 
       for _ in range(3):
         if cold: FLUSH.fill_(1)                      # 512 MB written in between: operands out of L2 / MALL
         buf.zero_()
-        ops.gemm_nt(a, w, out, epi, bias=bias if epi != EPI_NONE else None, resid=resid, tile_config=cfg, row_units=units)
+        aux = None
+        if "saved" in name:
+            aux = torch.empty(768, N, dtype=torch.bfloat16 if "act dtype" in name else torch.float32, device=dev)
+        ops.gemm_nt(a, w, out, epi, bias=bias if epi != EPI_NONE else None, resid=resid, tile_config=cfg, row_units=units,
+                    aux=aux, aux_row0=6304 if aux is not None else 0)
       torch.cuda.synchronize()
       show(name + (" -- operands COLD" if cold else ""), M, N, K, cfg)
     continue
