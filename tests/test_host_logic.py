@@ -278,3 +278,21 @@ def test_generated_k_loops_are_what_the_generators_emit(tmp_path):
         env = {k: v for k, v in os.environ.items() if not k.startswith("W4K_")}
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", gen), str(out)], env=env, stdout=subprocess.DEVNULL)
         assert out.read_text() == open(os.path.join(ROOT, "rpo_amd", "csrc", inc)).read(), f"{inc} is stale: re-run tools/{gen}"
+
+
+def test_stats_group_query_needs_no_gpu():
+    """rpo_gemm_stats_group is pure host logic (which partial-statistics layout a BIAS_RESID producer writes): 96 where the
+    224x96 kernel applies (ViT-B/16, 32 / 64 images, K <= 27 prompts), 64 for the 288x64 geometry (ViT-L/14, 16 images) and
+    wherever the generic tiles run."""
+    import torch
+    from rpo_amd import ops
+    g = ops.gemm_stats_group
+    assert g(7072, 768, 768, torch.bfloat16, (197, 24, 6304)) == 96
+    assert g(7072, 768, 3072, torch.float16, (197, 24, 6304)) == 96
+    assert g(2 * 7072, 768, 3072, torch.bfloat16, (197, 24, 2 * 6304)) == 96          # two rounds
+    assert g(7072, 768, 768, torch.bfloat16, None) == 64                               # no row units
+    assert g(7072, 768, 768, torch.float32, (197, 24, 6304)) == 64                     # f32 mode: generic kernels
+    assert g(32 * 245, 768, 768, torch.bfloat16, (197, 48, 32 * 197)) == 64            # K = 48: 245 rows per image
+    assert g(3536, 768, 768, torch.bfloat16, (197, 24, 3152)) == 64                    # 16 images: half a round
+    assert g(16 * 281, 1024, 4096, torch.bfloat16, (257, 24, 16 * 257)) == 64          # ViT-L/14: 288x64 tiles
+    assert g(7072, 768, 192, torch.bfloat16, (197, 24, 6304)) == 64                    # K = 192: 3 k-tiles, not admitted
