@@ -254,6 +254,13 @@ int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, const int64_t*
 int rpo_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
                  float grad_scale, int first_step, void* stream);
 
+/* The step as torch.cuda.amp.GradScaler.step takes it (trainers/rpo.py:298-304, PREC "amp"): if any element of g is Inf or
+ * NaN, nothing is updated.  found_inf: int32[2] on the device -- [0] = this step's flag, [1] += 1 per skipped step.  Here
+ * gradients are fp32 and never scaled, so this skip is all that is left of the scaler.  buf must start at zero (a
+ * skipped first step then needs no special case); first_step as in rpo_sgd_step.  One workgroup. */
+int rpo_sgd_step_guarded(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                         float grad_scale, int first_step, int32_t* found_inf, void* stream);
+
 /* fp32 -> act dtype copy with leading dimensions (weight packing at load time) */
 int rpo_convert(const float* src, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
                 int rows, int cols, void* stream);

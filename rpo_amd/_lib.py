@@ -86,6 +86,7 @@ SIGNATURES = {
     "rpo_head_fwd_bwd_act": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                      c_i32, c_i32, c_vp, c_vp]),
     "rpo_sgd_step": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "rpo_sgd_step_guarded": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_vp]),
     "rpo_convert": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "rpo_probe_mfma": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rpo_probe_peak_mfma": (c_i32, [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),

@@ -144,7 +144,8 @@ def act_dtype_for_prec(prec: str):
     and there is no loss scaling to reproduce.  "amp" (fp32 master weights + autocast + GradScaler) maps onto the
     same storage mode: autocast's fp16 GEMMs with fp32 accumulate are what the f16 mode computes, its fp32 master
     copy of the only trainable state is what the engine keeps anyway, and GradScaler's scale / unscale is the
-    identity on a gradient that is never stored in fp16.  bf16 remains available as `torch.bfloat16` (same MFMA
+    identity on a gradient that is never stored in fp16; what is left of the scaler -- skipping a step whose gradient
+    holds Inf / NaN -- is `RPO(..., amp=True)` (rpo_sgd_step_guarded).  bf16 remains available as `torch.bfloat16` (same MFMA
     rate, fp32 exponent range, 8 x the rounding error)."""
     import torch
     table = {"fp32": torch.float32, "fp16": torch.float16, "amp": torch.float16}

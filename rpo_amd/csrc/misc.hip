@@ -74,6 +74,35 @@ __global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, in
   p[i] = pi - lr * bi;
 }
 
+// The same step as GradScaler.step would take it (trainers/rpo.py:298-304, PREC amp): skipped as a whole when any gradient
+// is Inf / NaN.  One workgroup: the scan has to finish before the first update, and the trainable state is 30 720 floats.
+// found[0] = this step's flag, found[1] += 1 per skipped step.  The momentum buffer must start at zero: a skipped first
+// step then leaves the next one in the state torch's first step starts from.
+__global__ __launch_bounds__(1024) void sgd_guarded_kernel(float* p, const float* __restrict__ g, float* buf, int64_t n,
+                                                           float lr, float mom, float wd, float gs, int first,
+                                                           int32_t* found) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float gi = g[i];
+    mine |= !(fabsf(gi) <= 3.402823466e38f);                        // Inf or NaN
+  }
+  if (mine) bad = 1;
+  __syncthreads();
+  const int skip = bad;
+  if (threadIdx.x == 0) { found[0] = skip; found[1] += skip; }
+  if (skip) return;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float pi = p[i];
+    const float gi = gs * g[i] + wd * pi;
+    const float bi = first ? gi : mom * buf[i] + gi;
+    buf[i] = bi;
+    p[i] = pi - lr * bi;
+  }
+}
+
 template <typename TO>
 __global__ void convert_kernel(const float* __restrict__ src, int64_t lds, TO* dst, int64_t ldd, int rows,
                                int cols) {
@@ -467,6 +496,14 @@ extern "C" int rpo_sgd_step(float* p, const float* g, float* buf, int64_t n, flo
   if (!p || !g || !buf || n <= 0) return RPO_E_BADARG;
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_sgd_step_guarded(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
+                                    float grad_scale, int first_step, int32_t* found_inf, void* stream) {
+  if (!p || !g || !buf || !found_inf || n <= 0) return RPO_E_BADARG;
+  hipLaunchKernelGGL(sgd_guarded_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), p, g, buf, n, lr,
+                     momentum, wd, grad_scale, first_step, found_inf);
   return rpo_launch_status();
 }
 

@@ -241,6 +241,16 @@ def sgd_step(p, g, buf, lr: float, momentum: float, wd: float, grad_scale: float
     return p
 
 
+def sgd_step_guarded(p, g, buf, lr: float, momentum: float, wd: float, grad_scale: float, first_step: bool, found_inf):
+    """sgd_step, skipped as a whole when a gradient is Inf / NaN (GradScaler.step); found_inf: int32[2] device tensor."""
+    assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
+    assert found_inf.dtype == torch.int32 and found_inf.numel() >= 2 and found_inf.is_contiguous()
+    check(_lib.load().rpo_sgd_step_guarded(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, wd,
+                                           grad_scale, int(first_step), found_inf.data_ptr(), _stream()),
+          "rpo_sgd_step_guarded")
+    return p
+
+
 def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     assert src.dtype == torch.float32 and src.shape == dst.shape
     check(_lib.load().rpo_convert(src.data_ptr(), _ld(src), dst.data_ptr(), dtype_code(dst.dtype), _ld(dst),

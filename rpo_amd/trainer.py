@@ -56,8 +56,11 @@ class RPO:
     def __init__(self, cfg: RPOConfig, state_dict: Dict[str, np.ndarray], tokens: Optional[np.ndarray] = None,
                  optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
                  act_dtype: torch.dtype = torch.bfloat16, batch_size: int = 4, num_batches: int = 1,
-                 use_graph: bool = True, sync: Optional[GradSync] = None, prompts=None):
+                 use_graph: bool = True, sync: Optional[GradSync] = None, prompts=None, amp: bool = False):
         self.cfg = cfg
+        # PREC "amp" (trainers/rpo.py:298-304): what is left of GradScaler when gradients are fp32 -- a step whose
+        # gradient holds Inf / NaN is skipped on every rank (the flag is computed after the all-reduce)
+        self.amp = amp
         self.optim_cfg = optim or OptimConfig()
         self.device = torch.device(device)
         if self.device.index is None:
@@ -72,6 +75,7 @@ class RPO:
         self._steps = 0
         self._graph = None
         self.best_result = -float("inf")
+        self._found_inf = None                       # amp: int32[2] on the device (this step's flag, skipped steps)
         # trainers/rpo.py:287-288 turns on autograd anomaly detection ("nan detector"); there is no autograd graph
         # here, so the counterpart is a scan of loss + prompt gradients after the step (RPO_DETECT_ANOMALY=1 or
         # detect_anomaly=True; costs one D2H sync per step, so it is off in timed runs)
@@ -196,8 +200,14 @@ class RPO:
         else:
             eng.forward_backward(self._image, self._label)
         self.sync.all_reduce_sum(eng.grads)
-        ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
-                     self.sync.grad_scale, first_step=(self._steps == 0))
+        if self.amp:
+            if self._found_inf is None:
+                self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device)
+            ops.sgd_step_guarded(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
+                                 self.sync.grad_scale, first_step=(self._steps == 0), found_inf=self._found_inf)
+        else:
+            ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
+                         self.sync.grad_scale, first_step=(self._steps == 0))
         self._steps += 1
         eng.params_version += 1
         eng.text_f_version = -1

@@ -585,3 +585,29 @@ def test_end_to_end_few_shot_run_learns():
     acc = float((pred == np.array([t[1] for t in test])).mean())
     print('held-out accuracy', acc, 'loss', np.mean(first), '->', np.mean(last))
     assert acc >= 0.45, acc            # chance: 0.25 among the 4 classes used, 0.05 over the 19 class prompts
+
+
+def test_amp_mode_skips_a_step_with_nonfinite_gradients():
+    """PREC "amp" (trainers/rpo.py:298-304): GradScaler.step skips the optimiser step when the gradients hold Inf / NaN.
+    Gradients are fp32 and unscaled here, so that skip is all that is left of the scaler: RPO(amp=True)."""
+    from rpo_amd import synth
+    from rpo_amd.config import vit_b16
+    from rpo_amd.trainer import RPO
+    cfg = vit_b16(layers_v=2, layers_t=2, K=4)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    pr = synth.prompts(cfg, sd, seed=7)
+    img = torch.from_numpy(synth.images(cfg, 4, seed=1)).cuda()
+    lab = torch.from_numpy(synth.labels(cfg, 4, seed=2)).cuda()
+    plain = RPO(cfg, sd, toks, device="cuda:0", act_dtype=torch.float16, batch_size=4, prompts=pr)
+    amp = RPO(cfg, sd, toks, device="cuda:0", act_dtype=torch.float16, batch_size=4, prompts=pr, amp=True)
+    for _ in range(3):
+        plain.step_async(img, lab); amp.step_async(img, lab)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.engine.params, amp.engine.params), "finite gradients: amp must take the ordinary step"
+    before = amp.engine.params.clone()
+    bad = img.clone(); bad[1, 2, 100, 50] = float("nan")
+    amp.step_async(bad, lab); torch.cuda.synchronize()
+    assert torch.equal(amp.engine.params, before) and amp._found_inf.tolist() == [1, 1]
+    amp.step_async(img, lab); plain.step_async(img, lab); torch.cuda.synchronize()
+    assert amp._found_inf.tolist() == [0, 1] and torch.equal(plain.engine.params, amp.engine.params)

@@ -762,6 +762,39 @@ def test_sgd_broadcast_reduce_convert():
     assert torch.equal(c.cpu(), big[:24].to(torch.bfloat16))
 
 
+def test_sgd_step_guarded_skips_nonfinite_gradients():
+    """rpo_sgd_step_guarded = torch.cuda.amp.GradScaler.step on unscaled fp32 gradients (trainers/rpo.py:298-304): the
+    whole step is skipped when a gradient is Inf / NaN; otherwise the bits of rpo_sgd_step."""
+    o = ops()
+    n = 30720
+    p, g = rnd((n,), 41), rnd((n,), 42)
+    found = torch.zeros(2, dtype=torch.int32, device=dev())
+    pa, ba = p.to(dev()), torch.zeros(n, device=dev())
+    pb, bb = p.to(dev()), torch.zeros(n, device=dev())
+    gd = g.to(dev())
+    for step in range(3):
+        o.sgd_step(pa, gd, ba, 0.01, 0.9, 5e-4, 0.5, first_step=(step == 0))
+        o.sgd_step_guarded(pb, gd, bb, 0.01, 0.9, 5e-4, 0.5, first_step=(step == 0), found_inf=found)
+    assert torch.equal(pa, pb) and torch.equal(ba, bb) and found.tolist() == [0, 0]
+    for poison in (float("inf"), float("nan"), -float("inf")):
+        gbad = gd.clone(); gbad[n - 7] = poison
+        before_p, before_b = pb.clone(), bb.clone()
+        o.sgd_step_guarded(pb, gbad, bb, 0.01, 0.9, 5e-4, 0.5, first_step=False, found_inf=found)
+        assert torch.equal(pb, before_p) and torch.equal(bb, before_b) and found[0].item() == 1
+    assert found[1].item() == 3
+    o.sgd_step(pa, gd, ba, 0.01, 0.9, 5e-4, 0.5, first_step=False)
+    o.sgd_step_guarded(pb, gd, bb, 0.01, 0.9, 5e-4, 0.5, first_step=False, found_inf=found)
+    assert torch.equal(pa, pb) and found.tolist() == [0, 3]
+    # a skipped FIRST step: the next one starts from the zero momentum buffer, as torch's first step does
+    pc, bc = p.to(dev()), torch.zeros(n, device=dev())
+    gbad = gd.clone(); gbad[0] = float("nan")
+    o.sgd_step_guarded(pc, gbad, bc, 0.01, 0.9, 5e-4, 1.0, first_step=True, found_inf=found)
+    o.sgd_step_guarded(pc, gd, bc, 0.01, 0.9, 5e-4, 1.0, first_step=False, found_inf=found)
+    pd, bd = p.to(dev()), torch.zeros(n, device=dev())
+    o.sgd_step(pd, gd, bd, 0.01, 0.9, 5e-4, 1.0, first_step=True)
+    assert torch.equal(pc, pd) and torch.equal(bc, bd)
+
+
 def test_argument_errors_are_reported():
     from rpo_amd._lib import RPOLibraryError
     o = ops()
