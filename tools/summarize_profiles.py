@@ -54,9 +54,9 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
         lines.append(f"{'-> MFMA pipe utilisation':32s} {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (vals['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}\n")
     # One-wave-per-SIMD kernels: SQ_WAVE_CYCLES counts in units of 4 shader cycles, summed over the waves; with one wave
     # per SIMD, (SQ_WAVE_CYCLES * 4 / waves) is the lifetime of a workgroup in SHADER cycles (it matches the s_memtime
-    # total of rNN_gemm_timeline.txt), which is the right denominator for MFMA busy cycles per SIMD.  GRBM_GUI_ACTIVE
-    # ticks at ~2.5 GHz whatever the shader clock is (the chip runs these kernels at ~1.6-1.8 GHz), so the ratio above
-    # under-states the time the pipes are busy.
+    # total of rNN_gemm_timeline.txt): the denominator for "how busy are the pipes while the workgroup lives".
+    # GRBM_GUI_ACTIVE / 8 is the whole launch: dispatch ramp + wave lifetime + the end-of-kernel write-back of the output
+    # from L2, which no wave sees.
     waves = {"qkv": 252 * 4, "c_fc": 256 * 4, "c_proj": 256 * 4, "out_proj": 256 * 4}[shape]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "SQ_WAVE_CYCLES" in vals:
         life = vals["SQ_WAVE_CYCLES"] * 4 / waves
@@ -66,8 +66,8 @@ for shape in ("qkv", "out_proj", "c_fc", "c_proj"):
         lines.append(f"{'-> MFMA busy / wave lifetime':32s} {busy / life:.3f}\n")
         dur = kernel_us.get(shape)
         if dur:
-            lines.append(f"{'-> kernel duration under PMC':32s} {dur:.1f} us  (=> GRBM_GUI_ACTIVE at {vals.get('GRBM_GUI_ACTIVE', 0) / 8 / dur / 1e3:.2f} GHz, "
-                         f"shader clock >= {life / dur / 1e3:.2f} GHz)\n")
+            lines.append(f"{'-> kernel duration under PMC':32s} {dur:.1f} us  (GRBM_GUI_ACTIVE / 8 = {vals.get('GRBM_GUI_ACTIVE', 0) / 8:.0f} cycles = "
+                         f"{vals.get('GRBM_GUI_ACTIVE', 0) / 8 / dur / 1e3:.2f} GHz x duration; wave lifetime / duration = {life / dur / 1e3:.2f} GHz)\n")
     if "TCC_HIT_sum" in vals:
         lines.append(f"{'-> L2 hit rate':32s} {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.3f}\n")
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
