@@ -146,6 +146,13 @@ extern __device__ unsigned long long* g_timeline;
     if (g_timeline != nullptr && threadIdx.x == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)   \
       g_timeline[(blockIdx.x / 97) * 64 + (slot)] = __builtin_amdgcn_s_memtime();                     \
   } while (0)
+// the constant 100 MHz counter next to s_memtime: (delta s_memtime) / (delta s_memrealtime) * 100 MHz = the shader clock
+#define RPO_STAMP_RT(slot)                                                                            \
+  do {                                                                                                \
+    if (g_timeline != nullptr && threadIdx.x == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)   \
+      g_timeline[(blockIdx.x / 97) * 64 + (slot)] = __builtin_amdgcn_s_memrealtime();                 \
+  } while (0)
 #else
 #define RPO_STAMP(slot) do { } while (0)
+#define RPO_STAMP_RT(slot) do { } while (0)
 #endif

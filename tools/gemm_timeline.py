@@ -30,7 +30,9 @@ def show(name, M, N, K, cfg):
         deltas = [int(r[2 + i] - r[2 + i - 1]) for i in range(1, min(nk, 14))]
         if cfg in (8, 10, 11):
             nk32 = K // 32
-            print(f" wg {b*97:5d}: start->loop {int(r[2]-r[0]):6d} | loop {int(r[60]-r[2]):6d} = {nk32} tiles x {int(r[60]-r[2])//nk32} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}")
+            rt = int(r[63] - r[62])                    # 100 MHz ticks over the same span
+            clk = f" | {int(r[61]-r[0]) / rt * 0.1:.2f} GHz over {rt / 100:.1f} us" if rt > 0 else ""
+            print(f" wg {b*97:5d}: start->loop {int(r[2]-r[0]):6d} | loop {int(r[60]-r[2]):6d} = {nk32} tiles x {int(r[60]-r[2])//nk32} | epilogue {int(r[61]-r[60]):6d} | total {int(r[61]-r[0])}{clk}")
             continue
         if cfg == 7:
             nk32 = K // 32
