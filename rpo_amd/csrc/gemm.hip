@@ -370,7 +370,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       const int m = m0 + row;
       const uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
       if (m < p.M && n < p.N)
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
+        store_out16(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n), v);
     }
   } else {
 #pragma unroll
