@@ -234,6 +234,38 @@ class OracleRPO:
 
 
 # ---------------------------------------------------------------------------
+# the unmasked towers: plain CLIP inference (clip/model.py:344-372), as trainers/zsclip.py:58-63 and the sibling
+# trainers' CustomCLIP.forward (trainers/coop.py:196-208) use them
+# ---------------------------------------------------------------------------
+def plain_clip_forward(state_dict, image, tokens, patch: int):
+    """CLIP.forward(image, text) -> (logits_per_image [B, n_cls], image_features [B, e], text_features [n_cls, e]);
+    features before normalisation.  Image tower: every token reads every token (clip/model.py:227-240); text tower:
+    causal mask over the whole context (:287-292, :347-360), feature at the EOT position (= argmax of the ids)."""
+    sd = {k: _t(v).float() for k, v in state_dict.items()}
+    image, tokens = _t(image).float(), _t(tokens).long()
+    d_t, d_v = sd["ln_final.weight"].shape[0], sd["visual.class_embedding"].shape[0]
+    B = image.shape[0]
+    emb = F.conv2d(image, sd["visual.conv1.weight"], stride=patch)
+    emb = emb.reshape(B, emb.shape[1], -1).permute(0, 2, 1)
+    x = torch.cat([sd["visual.class_embedding"].repeat(B, 1, 1), emb], dim=1) + sd["visual.positional_embedding"]
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"]).permute(1, 0, 2)
+    S = x.shape[0]
+    for blk in _blocks(sd, "visual.transformer.resblocks."):
+        x = res_block(x, blk, d_v // HEAD_DIM, torch.zeros(S, S))
+    img_f = layer_norm(x.permute(1, 0, 2)[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
+    t = (sd["token_embedding.weight"][tokens] + sd["positional_embedding"]).permute(1, 0, 2)
+    T = t.shape[0]
+    causal = torch.full((T, T), float("-inf")).triu_(1)
+    for blk in _blocks(sd, "transformer.resblocks."):
+        t = res_block(t, blk, d_t // HEAD_DIM, causal)
+    t = layer_norm(t.permute(1, 0, 2), sd["ln_final.weight"], sd["ln_final.bias"])
+    txt_f = t[torch.arange(t.shape[0]), tokens.argmax(dim=-1)] @ sd["text_projection"]
+    a = img_f / img_f.norm(dim=-1, keepdim=True)
+    b = txt_f / txt_f.norm(dim=-1, keepdim=True)
+    return sd["logit_scale"].exp() * a @ b.t(), img_f, txt_f
+
+
+# ---------------------------------------------------------------------------
 # optimiser (torch.optim.SGD restated; Dassl's defaults are not in the tree, so
 # momentum / weight decay / dampening are explicit -- SURVEY.md section 8c)
 # ---------------------------------------------------------------------------

@@ -90,6 +90,9 @@ class Engine:
             self._alloc()
         self.text_cache_ready = False
         self._stats_group = {}          # batch size -> columns per partial LayerNorm statistic (64 or 96)
+        self.img_cls_f = None
+        self.plain_text_f = None
+        self.text_x_final = None
         self._eval_graphs = {}          # batch size -> (captured image tower + head, its static input)
         self.probe = None               # optional callable(name) -> context manager bracketing one launch (bench.py)
         self.text_f_version = -1        # prompts version the cached eval text features belong to
@@ -254,6 +257,8 @@ class Engine:
             ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, h)
             ops.gemm_nt(h, blk.w_fc, g, EPI_BIAS_QGELU, bias=blk.b_fc, aux=None, aux_row0=Rf)
             ops.gemm_nt(g, blk.w_proj, x, EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
+        self.text_x_final = x                       # output of the last block for the frozen tokens (forward_plain)
+        self.plain_text_f = None
         self.text_cache_ready = True
 
     def _timed(self, name: str):
@@ -291,7 +296,7 @@ class Engine:
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
         ops.gemm_nt(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 
-    def _image_forward(self, image: torch.Tensor, train: bool) -> None:
+    def _image_forward(self, image: torch.Tensor, train: bool, full_last: bool = False) -> None:
         cfg = self.cfg
         B, N, K, dv, H = image.shape[0], cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
         Rf, Rp = B * N, B * K
@@ -330,7 +335,7 @@ class Engine:
             epi_in = EPI_LN_BIAS if folded_in else EPI_BIAS
             lnk = lambda r0, r1, c0, c1: (dict(ln_stats=st_proj[r0:r1], ln_colsum=blk.s_in[c0:c1], ln_group=g_proj)
                                           if folded_in else {})
-            if l < last:
+            if l < last or full_last:
                 # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
                 with self._timed("in_proj"):
                     ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv))
@@ -347,6 +352,7 @@ class Engine:
                                       q_first=N)
                 lo = Rf
             timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
+            # (unless full_last: forward_plain needs the CLS row of the last block)
             # the last block works on the prompt rows only: plain tiles, 64-column statistics
             whole = lo == 0
             un_o, go, so = (u_out, g_out, st_out) if whole else (None, 64, st64)
@@ -496,6 +502,34 @@ class Engine:
         if self.act == torch.float32:
             return {}
         return dict(d_img_f_act=self.d_img_f_a[:B * self.cfg.K], d_text_f_act=self.d_text_f_a)
+
+    def forward_plain(self, image: torch.Tensor) -> torch.Tensor:
+        """Plain CLIP inference, logits[B, n_cls] = CLIP.forward(image, tokens) (clip/model.py:344-372): what
+        trainers/zsclip.py:58-63 computes, and the towers the sibling trainers call (trainers/coop.py:196-208).
+        No token reads a prompt (section 2 of DESIGN.md), so the frozen rows of this engine ARE the unmasked towers:
+        the image feature is ln_post + proj of the CLS row of a complete last block, the text feature the EOT row of the
+        frozen-token pass that fills the K / V cache.  The prompts play no part."""
+        cfg = self.cfg
+        B = self._check(image)
+        N, dv, e, n = cfg.n_frozen, cfg.d_v, cfg.embed, cfg.n_cls
+        if not self.text_cache_ready:
+            self.cache_text_kv()
+        if self.plain_text_f is None:
+            rows = torch.arange(n, device=self.dev) * self.Lmax + (self.len_i32.to(torch.int64) - 1)   # EOT positions
+            eot = self.text_x_final.index_select(0, rows).contiguous()
+            y = torch.empty(n, cfg.d_t, dtype=self.act, device=self.dev)
+            ops.layernorm_fwd(eot, self.ln_final[0], self.ln_final[1], y)
+            self.plain_text_f = torch.empty(n, e, dtype=torch.float32, device=self.dev)
+            ops.gemm_nt(y, self.text_proj_t, self.plain_text_f, EPI_NONE)
+        self._image_forward(image, train=False, full_last=True)
+        cls_rows = self.x[-1][:B * N].view(B, N, dv)[:, 0, :]                  # [B, dv], row stride N * dv
+        ops.layernorm_fwd(cls_rows, self.ln_post[0], self.ln_post[1], self.y_post[:B])
+        if self.img_cls_f is None:
+            self.img_cls_f = torch.empty(self.max_batch, e, dtype=torch.float32, device=self.dev)
+        ops.gemm_nt(self.y_post[:B], self.img_proj_t, self.img_cls_f[:B], EPI_NONE)
+        ops.head_fwd_bwd(self.img_cls_f[:B].view(B, 1, e), self.plain_text_f.view(n, 1, e), None, self.logit_scale_exp,
+                         self.logits[:B], None, None, None, self.head_ws)
+        return self.logits[:B]
 
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
         """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in

@@ -611,3 +611,29 @@ def test_amp_mode_skips_a_step_with_nonfinite_gradients():
     assert torch.equal(amp.engine.params, before) and amp._found_inf.tolist() == [1, 1]
     amp.step_async(img, lab); plain.step_async(img, lab); torch.cuda.synchronize()
     assert amp._found_inf.tolist() == [0, 1] and torch.equal(plain.engine.params, amp.engine.params)
+
+
+@pytest.mark.parametrize("tag,depth,B", [("d2_b3", 2, 3), ("d12_b2", 12, 2)])
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_plain_clip_inference_matches_reference_clip_forward(tag, depth, B, mode):
+    """The unmasked towers (trainers/zsclip.py:58-63, trainers/coop.py:196-208 -> clip/model.py:344-372): logits of
+    rpo_amd.zeroshot.ZeroshotCLIP against the reference's own CLIP.forward (tests/golden/ref_plainclip_*.npz)."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.zeroshot import ZeroshotCLIP
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_plainclip_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[mode]
+    m = ZeroshotCLIP(sd, device="cuda:0", act_dtype=dt, max_batch=4)
+    image = torch.from_numpy(synth.images(cfg, B))
+    logits = m.model_inference(image).cpu().numpy()
+    tol = {"f32": 1e-3, "f16": 1e-2, "bf16": 0.12}[mode]
+    err = np.abs(logits - gold["logits"]).max()
+    assert err <= tol, f"{mode}: logits differ from the reference by {err:.3e} (bound {tol})"
+    assert (logits.argmax(1) == gold["logits"].argmax(1)).all()
+    again = m.model_inference(image).cpu().numpy()                  # cached text features, same bits
+    assert np.array_equal(again, logits)
+    img_f = m.engine.img_cls_f[:B].cpu().numpy()
+    if mode == "f32":
+        assert np.abs(img_f - gold["image_features"]).max() <= 1e-4 * max(1.0, np.abs(gold["image_features"]).max())
+        assert np.abs(m.engine.plain_text_f.cpu().numpy() - gold["text_features"]).max() <= 1e-4 * max(1.0, np.abs(gold["text_features"]).max())

@@ -95,3 +95,21 @@ def test_algorithmic_flops_match_survey():
     f, b = flops_image(vit_l14())
     assert round(f / 1e9, 2) == 174.75 and round(b / 1e9, 2) == 12.72
     assert round(flops_text(vit_l14(), lens) / 1e9, 2) == 130.51
+
+
+@pytest.mark.parametrize("tag,depth,B", [("d2_b3", 2, 3), ("d12_b2", 12, 2)])
+def test_plain_clip_oracle_matches_reference_clip_forward(tag, depth, B):
+    """The unmasked towers (clip/model.py:344-372; what trainers/zsclip.py and the sibling trainers run): the oracle's
+    restatement against logits / features produced by the reference's own CLIP.forward (tools/make_golden_plainclip.py)."""
+    import os
+    from rpo_amd import synth
+    from rpo_amd.config import vit_b16
+    from oracle.rpo_oracle import plain_clip_forward
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_plainclip_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    assert gold["weights_crc"].item().decode() == synth.state_dict_checksum(sd), "fixture made from other weights"
+    logits, img_f, txt_f = plain_clip_forward(sd, synth.images(cfg, B), synth.oxford_pets_base_tokens(), cfg.patch)
+    assert np.abs(logits.numpy() - gold["logits"]).max() <= 3e-5
+    assert np.abs(img_f.numpy() - gold["image_features"]).max() <= 2e-5 * max(1.0, np.abs(gold["image_features"]).max())
+    assert np.abs(txt_f.numpy() - gold["text_features"]).max() <= 2e-5 * max(1.0, np.abs(gold["text_features"]).max())

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Golden vectors of the UNMASKED towers (plain CLIP inference) from the real reference: `clip.model.CLIP.forward`
+(clip/model.py:344-372), which is what trainers/zsclip.py:58-63 and the sibling trainers' CustomCLIP.forward
+(trainers/coop.py:196-208) run.  Same synthetic weights / images / token ids as tools/make_golden.py; writes
+tests/golden/ref_plainclip_*.npz.  Runs in the build container only (needs /root/reference)."""
+import os, sys
+import numpy as np, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from make_golden import _reference, REPO          # noqa: E402  (stubs the absent dassl / yacs imports, nothing copied)
+from rpo_amd import synth                         # noqa: E402
+from rpo_amd.config import vit_b16                # noqa: E402
+
+ref_clip, CLIP, _ = _reference()
+toks = synth.oxford_pets_base_tokens()
+for tag, depth, B in (("d2_b3", 2, 3), ("d12_b2", 12, 2)):
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    model = CLIP(cfg.embed, cfg.image_size, cfg.layers_v, cfg.d_v, cfg.patch, cfg.context, cfg.vocab, cfg.d_t,
+                 cfg.heads_t, cfg.layers_t).float().eval()
+    res = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    image = torch.from_numpy(synth.images(cfg, B))
+    text = torch.from_numpy(toks)
+    with torch.no_grad():
+        logits, _ = model(image, text)
+        img_f, txt_f = model.encode_image(image), model.encode_text(text)
+    path = os.path.join(REPO, "tests", "golden", f"ref_plainclip_{tag}.npz")
+    np.savez_compressed(path, logits=logits.numpy(), image_features=img_f.numpy(), text_features=txt_f.numpy(),
+                        weights_crc=np.bytes_(synth.state_dict_checksum(sd)))
+    print(tag, "|logits|max", float(logits.abs().max()), os.path.getsize(path), "bytes")
