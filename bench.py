@@ -223,6 +223,25 @@ def time_eval(cfg, sd, toks, prompts, act, dev, batch: int, iters: int = 20):
             "note": "image tower + head replayed as one HIP graph; text features cached after the first batch"}
 
 
+def time_zeroshot(cfg, sd, toks, act, dev, batch: int, iters: int = 20):
+    """the unmasked towers (trainers/zsclip.py:58-63): plain CLIP logits at the
+    reference's test batch, text features computed once; launched eagerly (no graph)."""
+    from rpo_amd.zeroshot import ZeroshotCLIP
+    m = ZeroshotCLIP(sd, toks, dev, act, max_batch=batch)
+    img = torch.from_numpy(synth.images(cfg, batch, seed=77)).to(dev)
+    for _ in range(3):
+        m.engine.forward_plain(img)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        m.engine.forward_plain(img)
+    e.record()
+    e.synchronize()
+    ms = s.elapsed_time(e) / iters
+    return {"batch": batch, "ms_per_batch": round(ms, 3), "images_per_sec": round(1e3 * batch / ms, 1),
+            "note": "plain CLIP inference on the frozen rows of the same engine; eager launches"}
+
+
 def time_input_pipeline(dev, batch: int, iters: int = 20):
     """the train transform (random_resized_crop + flip + normalize) of `batch` decoded
     375x500 uint8 images per call, host packing + H2D + kernels (`with_h2d`) and kernels alone on a resident
@@ -428,6 +447,7 @@ def main() -> None:
             out["input_pipeline"] = time_input_pipeline(dev, args.batch)
         if args.eval_batch > 0:
             out["eval"] = time_eval(cfg, sd, toks, prompts, act, dev, args.eval_batch)
+            out["zeroshot"] = time_zeroshot(cfg, sd, toks, act, dev, args.eval_batch)
         if args.dtype != "f32" and sync.world_size == 1 and not args.no_precision:
             del tr
             torch.cuda.empty_cache()
