@@ -237,10 +237,13 @@ class OracleRPO:
 # the unmasked towers: plain CLIP inference (clip/model.py:344-372), as trainers/zsclip.py:58-63 and the sibling
 # trainers' CustomCLIP.forward (trainers/coop.py:196-208) use them
 # ---------------------------------------------------------------------------
-def plain_clip_forward(state_dict, image, tokens, patch: int):
+def plain_clip_forward(state_dict, image, tokens, patch: int, ctx=None):
     """CLIP.forward(image, text) -> (logits_per_image [B, n_cls], image_features [B, e], text_features [n_cls, e]);
     features before normalisation.  Image tower: every token reads every token (clip/model.py:227-240); text tower:
-    causal mask over the whole context (:287-292, :347-360), feature at the EOT position (= argmax of the ids)."""
+    causal mask over the whole context (:287-292, :347-360), feature at the EOT position (= argmax of the ids).
+    ctx [n_ctx, d_t]: CoOp's learned context (trainers/coop.py:117-134, class token at the end, generic context): the
+    embeddings of positions 1 .. n_ctx of every class are replaced by it before the positional embedding is added
+    (TextEncoder.forward, :47-58)."""
     sd = {k: _t(v).float() for k, v in state_dict.items()}
     image, tokens = _t(image).float(), _t(tokens).long()
     d_t, d_v = sd["ln_final.weight"].shape[0], sd["visual.class_embedding"].shape[0]
@@ -253,7 +256,11 @@ def plain_clip_forward(state_dict, image, tokens, patch: int):
     for blk in _blocks(sd, "visual.transformer.resblocks."):
         x = res_block(x, blk, d_v // HEAD_DIM, torch.zeros(S, S))
     img_f = layer_norm(x.permute(1, 0, 2)[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
-    t = (sd["token_embedding.weight"][tokens] + sd["positional_embedding"]).permute(1, 0, 2)
+    emb_t = sd["token_embedding.weight"][tokens]
+    if ctx is not None:
+        ctx = ctx if isinstance(ctx, torch.Tensor) else _t(ctx).float()
+        emb_t = torch.cat([emb_t[:, :1], ctx.unsqueeze(0).expand(emb_t.shape[0], -1, -1), emb_t[:, 1 + ctx.shape[0]:]], dim=1)
+    t = (emb_t + sd["positional_embedding"]).permute(1, 0, 2)
     T = t.shape[0]
     causal = torch.full((T, T), float("-inf")).triu_(1)
     for blk in _blocks(sd, "transformer.resblocks."):
@@ -263,6 +270,15 @@ def plain_clip_forward(state_dict, image, tokens, patch: int):
     a = img_f / img_f.norm(dim=-1, keepdim=True)
     b = txt_f / txt_f.norm(dim=-1, keepdim=True)
     return sd["logit_scale"].exp() * a @ b.t(), img_f, txt_f
+
+
+def coop_loss_and_grad(state_dict, image, tokens, ctx, label, patch: int):
+    """trainers/coop.py:266-270 (fp32 branch): logits, cross-entropy and d loss / d ctx."""
+    c = _t(ctx).float().clone().requires_grad_(True)
+    logits, _, _ = plain_clip_forward(state_dict, image, tokens, patch, ctx=c)
+    loss = F.cross_entropy(logits, _t(label).long())
+    loss.backward()
+    return logits.detach(), loss.detach(), c.grad.clone()
 
 
 # ---------------------------------------------------------------------------

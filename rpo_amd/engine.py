@@ -155,6 +155,7 @@ class Engine:
         # make_prompts (trainers/rpo.py:135-136): tok_emb[ids] + pos, kept for the frozen tokens only
         tx = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][None]
         self.text_x_frozen = self._f32(tx[:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
+        self.text_pos = self._f32(sd["positional_embedding"][:self.Lmax])
 
     # ------------------------------------------------------------------ workspace
     def _alloc(self) -> None:
@@ -502,6 +503,19 @@ class Engine:
         if self.act == torch.float32:
             return {}
         return dict(d_img_f_act=self.d_img_f_a[:B * self.cfg.K], d_text_f_act=self.d_text_f_a)
+
+    def set_context(self, ctx) -> None:
+        """CoOp's learned context (trainers/coop.py:117-134, generic context, class token at the end): the input
+        embeddings of positions 1 .. n_ctx of every class become ctx + positional embedding (TextEncoder.forward,
+        :47-58).  Affects forward_plain (and everything that reads the frozen-token pass) from the next call on."""
+        c = torch.as_tensor(np.asarray(ctx, dtype=np.float32), device=self.dev)
+        n_ctx = c.shape[0]
+        assert c.ndim == 2 and c.shape[1] == self.cfg.d_t and 1 + n_ctx < self.Lmax, "ctx: [n_ctx, d_t], 1 + n_ctx < prompt length"
+        x = self.text_x_frozen.view(self.cfg.n_cls, self.Lmax, self.cfg.d_t)
+        x[:, 1:1 + n_ctx] = (c + self.text_pos[1:1 + n_ctx])[None]
+        self.text_cache_ready = False
+        self.plain_text_f = None
+        self.text_f_version = -1
 
     def forward_plain(self, image: torch.Tensor) -> torch.Tensor:
         """Plain CLIP inference, logits[B, n_cls] = CLIP.forward(image, tokens) (clip/model.py:344-372): what

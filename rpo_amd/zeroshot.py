@@ -36,6 +36,13 @@ class ZeroshotCLIP:
         with torch.cuda.device(self.engine.dev):
             self.engine.cache_text_kv()                                       # text features: once (zsclip.py:48-53)
 
+    def set_context(self, ctx) -> None:
+        """Evaluate CoOp-style learned context vectors (trainers/coop.py:117-134: generic context [n_ctx, d_t], class
+        token at the end): `tokens` must then be the ids of the reference's "X X .. name." prompts."""
+        with torch.cuda.device(self.engine.dev):
+            self.engine.set_context(ctx)
+            self.engine.cache_text_kv()
+
     @torch.no_grad()
     def model_inference(self, image: torch.Tensor) -> torch.Tensor:
         """trainers/zsclip.py:58-63 -> logits [B, n_cls] (fp32, on the device)."""

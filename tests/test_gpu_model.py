@@ -637,3 +637,25 @@ def test_plain_clip_inference_matches_reference_clip_forward(tag, depth, B, mode
     if mode == "f32":
         assert np.abs(img_f - gold["image_features"]).max() <= 1e-4 * max(1.0, np.abs(gold["image_features"]).max())
         assert np.abs(m.engine.plain_text_f.cpu().numpy() - gold["text_features"]).max() <= 1e-4 * max(1.0, np.abs(gold["text_features"]).max())
+
+
+@pytest.mark.parametrize("tag,depth,B", [("d2_b3_ctx4", 2, 3), ("d2_b2_ctx16", 2, 2)])
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_coop_context_inference_matches_reference_trainer(tag, depth, B, mode):
+    """CoOp's forward (trainers/coop.py:117-134,196-208): learned context vectors in front of the class name on the
+    unmasked towers -- logits against the reference's own coop.CustomCLIP (tests/golden/ref_coop_*.npz)."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.zeroshot import ZeroshotCLIP
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_coop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    dt = {"f32": torch.float32, "f16": torch.float16}[mode]
+    m = ZeroshotCLIP(sd, gold["tokenized_prompts"], device="cuda:0", act_dtype=dt, max_batch=4)
+    image = torch.from_numpy(synth.images(cfg, B))
+    before = m.model_inference(image).cpu().numpy()               # "X X .." placeholders: not the answer
+    m.set_context(gold["ctx"])
+    logits = m.model_inference(image).cpu().numpy()
+    tol = {"f32": 1e-3, "f16": 1e-2}[mode]
+    err = np.abs(logits - gold["logits"]).max()
+    assert err <= tol, f"{mode}: logits differ from the reference by {err:.3e} (bound {tol})"
+    assert np.abs(before - gold["logits"]).max() > 10 * tol

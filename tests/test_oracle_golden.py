@@ -113,3 +113,20 @@ def test_plain_clip_oracle_matches_reference_clip_forward(tag, depth, B):
     assert np.abs(logits.numpy() - gold["logits"]).max() <= 3e-5
     assert np.abs(img_f.numpy() - gold["image_features"]).max() <= 2e-5 * max(1.0, np.abs(gold["image_features"]).max())
     assert np.abs(txt_f.numpy() - gold["text_features"]).max() <= 2e-5 * max(1.0, np.abs(gold["text_features"]).max())
+
+
+@pytest.mark.parametrize("tag,depth,B,n_ctx", [("d2_b3_ctx4", 2, 3, 4), ("d2_b2_ctx16", 2, 2, 16)])
+def test_coop_oracle_matches_reference_trainer(tag, depth, B, n_ctx):
+    """CoOp (trainers/coop.py:117-134,196-208,266-270): logits, loss and the gradient of the context vectors of the
+    oracle against the reference's own CustomCLIP + cross_entropy + backward (tools/make_golden_plainclip.py)."""
+    import os
+    from oracle.rpo_oracle import coop_loss_and_grad
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_coop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    assert gold["weights_crc"].item().decode() == synth.state_dict_checksum(sd)
+    assert gold["ctx"].shape == (n_ctx, cfg.d_t)
+    logits, loss, g = coop_loss_and_grad(sd, synth.images(cfg, B), gold["tokenized_prompts"], gold["ctx"], gold["label"], cfg.patch)
+    assert np.abs(logits.numpy() - gold["logits"]).max() <= 3e-5
+    assert abs(float(loss) - float(gold["loss"])) <= 1e-5
+    assert np.abs(g.numpy() - gold["ctx_grad"]).max() <= 2e-5 * np.abs(gold["ctx_grad"]).max()

@@ -30,3 +30,39 @@ for tag, depth, B in (("d2_b3", 2, 3), ("d12_b2", 12, 2)):
     np.savez_compressed(path, logits=logits.numpy(), image_features=img_f.numpy(), text_features=txt_f.numpy(),
                         weights_crc=np.bytes_(synth.state_dict_checksum(sd)))
     print(tag, "|logits|max", float(logits.abs().max()), os.path.getsize(path), "bytes")
+
+# ---- CoOp (trainers/coop.py): learned context vectors in front of the class name, otherwise the unmasked towers --------
+# logits, loss and d loss / d ctx of the reference's own CustomCLIP + F.cross_entropy for a GIVEN ctx (generic context,
+# class token at the end: configs/trainers/CoOp/vit_b16_ep50.yaml defaults).  The token ids of its "X X .. name." prompts
+# are saved with the vectors: they are data, and the BPE tokenizer is out of scope on the other side.
+import types
+import torch.nn.functional as F
+import trainers.coop as ref_coop                  # noqa: E402  (same stubs as trainers/rpo.py)
+from rpo_amd.config import OXFORD_PETS_BASE_CLASSES  # noqa: E402
+
+ns = types.SimpleNamespace
+for tag, depth, B, n_ctx in (("d2_b3_ctx4", 2, 3, 4), ("d2_b2_ctx16", 2, 2, 16)):
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    clip_model = CLIP(cfg.embed, cfg.image_size, cfg.layers_v, cfg.d_v, cfg.patch, cfg.context, cfg.vocab, cfg.d_t,
+                      cfg.heads_t, cfg.layers_t).float()
+    clip_model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    rcfg = ns(TRAINER=ns(COOP=ns(N_CTX=n_ctx, CTX_INIT="", CSC=False, CLASS_TOKEN_POSITION="end", PREC="fp32")),
+              INPUT=ns(SIZE=(cfg.image_size, cfg.image_size)))
+    model = ref_coop.CustomCLIP(rcfg, list(OXFORD_PETS_BASE_CLASSES), clip_model)
+    for name, p in model.named_parameters():
+        p.requires_grad_("prompt_learner" in name)             # trainers/coop.py:228-230
+    ctx = (np.random.default_rng(11).standard_normal((n_ctx, cfg.d_t)) * 0.02).astype(np.float32)
+    model.prompt_learner.ctx.data = torch.from_numpy(ctx.copy())
+    image = torch.from_numpy(synth.images(cfg, B))
+    label = torch.from_numpy(synth.labels(cfg, B))
+    logits = model(image)
+    loss = F.cross_entropy(logits, label)                     # trainers/coop.py:268-269
+    loss.backward()
+    path = os.path.join(REPO, "tests", "golden", f"ref_coop_{tag}.npz")
+    np.savez_compressed(path, logits=logits.detach().numpy(), loss=np.float32(loss.item()), ctx=ctx,
+                        ctx_grad=model.prompt_learner.ctx.grad.numpy(), label=label.numpy(),
+                        tokenized_prompts=model.tokenized_prompts.numpy().astype(np.int64),
+                        weights_crc=np.bytes_(synth.state_dict_checksum(sd)))
+    print("coop", tag, "loss", float(loss), "|ctx_grad|max", float(model.prompt_learner.ctx.grad.abs().max()),
+          os.path.getsize(path), "bytes")
