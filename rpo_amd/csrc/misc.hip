@@ -30,6 +30,39 @@ __global__ void im2col_kernel(const float* __restrict__ img, TO* out, int64_t ld
     for (int k = 3 * p * p; k < ldo; ++k) ActIO<TO>::st(out + m * ldo + k, 0.f);
 }
 
+// patch % 8 == 0 (ViT-B/16, /32): one thread per 8 consecutive pixels -- two 16-B loads, one 16-B store in the 16-bit
+// modes (the 2-pixel version above issues 4-B stores: 15 us for the 19 MB image batch at B = 32, this one 3x fewer
+// instructions per byte).  Same values, same layout.
+template <typename TO>
+__global__ void im2col8_kernel(const float* __restrict__ img, TO* out, int64_t ldo, int B, int H, int W,
+                               int p, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // ((b*3 + c)*H + y) * (W/8) + x8
+  if (idx >= total) return;
+  const int w8 = W >> 3;
+  const int x = (int)(idx % w8) * 8;
+  const int64_t row = idx / w8;
+  const int y = (int)(row % H);
+  const int c = (int)((row / H) % 3);
+  const int b = (int)(row / (3 * (int64_t)H));
+  const float4 v0 = *reinterpret_cast<const float4*>(img + row * W + x);
+  const float4 v1 = *reinterpret_cast<const float4*>(img + row * W + x + 4);
+  const int g = W / p;
+  const int py = y / p, ky = y - py * p, px = x / p, kx = x - px * p;
+  const int64_t m = ((int64_t)b * (H / p) + py) * g + px;
+  TO* dst = out + m * ldo + (c * p + ky) * p + kx;
+  if constexpr (sizeof(TO) == 2) {
+    uint4 o;
+    o.x = pack2<TO>(v0.x, v0.y); o.y = pack2<TO>(v0.z, v0.w);
+    o.z = pack2<TO>(v1.x, v1.y); o.w = pack2<TO>(v1.z, v1.w);
+    *reinterpret_cast<uint4*>(dst) = o;
+  } else {
+    *reinterpret_cast<float4*>(dst) = v0;
+    *reinterpret_cast<float4*>(dst + 4) = v1;
+  }
+  if (c == 2 && ky == p - 1 && kx + 8 >= p)       // last pixels of the patch: zero the K padding
+    for (int k = 3 * p * p; k < ldo; ++k) ActIO<TO>::st(out + m * ldo + k, 0.f);
+}
+
 __global__ void assemble_kernel(float* x, int64_t ldx, const float* __restrict__ cls,
                                 const float* __restrict__ pos0, const float* __restrict__ prompt, int B, int N,
                                 int Kp, int d) {
@@ -404,8 +437,25 @@ extern "C" int rpo_im2col_patches(const float* img, void* out, int out_dtype, in
   if (!img || !out || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return RPO_E_BADARG;
   if (H % patch || W % patch || patch % 2 || ldo < 3 * patch * patch) return RPO_E_SHAPE;
   if (reinterpret_cast<uintptr_t>(img) % 8) return RPO_E_ALIGN;
-  const int64_t total = (int64_t)B * 3 * H * (W / 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int esz = out_dtype == RPO_F32 ? 4 : 2;
+  if (patch % 8 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+      (ldo * esz) % 16 == 0) {
+    const int64_t total8 = (int64_t)B * 3 * H * (W / 8);
+    const unsigned blocks8 = (unsigned)((total8 + 255) / 256);
+    if (out_dtype == RPO_BF16)
+      hipLaunchKernelGGL(im2col8_kernel<bf16_t>, dim3(blocks8), dim3(256), 0, s, img,
+                         static_cast<bf16_t*>(out), ldo, B, H, W, patch, total8);
+    else if (out_dtype == RPO_F16)
+      hipLaunchKernelGGL(im2col8_kernel<f16_t>, dim3(blocks8), dim3(256), 0, s, img,
+                         static_cast<f16_t*>(out), ldo, B, H, W, patch, total8);
+    else if (out_dtype == RPO_F32)
+      hipLaunchKernelGGL(im2col8_kernel<float>, dim3(blocks8), dim3(256), 0, s, img,
+                         static_cast<float*>(out), ldo, B, H, W, patch, total8);
+    else return RPO_E_DTYPE;
+    return rpo_launch_status();
+  }
+  const int64_t total = (int64_t)B * 3 * H * (W / 2);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   if (out_dtype == RPO_BF16)
     hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, img,
