@@ -103,13 +103,29 @@ __device__ __forceinline__ float wave_max(float v) {
 // (v_exp_f32 + v_rcp_f32, ~1 ulp each): libm's expf plus an IEEE division cost ~40 VALU instructions per
 // element, which made the c_fc epilogue ~20 % of that GEMM (s_memtime: 8-12 k cycles per 128x128 tile).
 #define RPO_QG 1.702f
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#define RPO_QG_L2 (-2.4554669595930156f)           // -1.702 * log2(e): sigmoid(1.702 u) = 1 / (1 + 2^(RPO_QG_L2 * u))
+__device__ __forceinline__ float qg_sigmoid(float u) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(RPO_QG_L2 * u));
 }
-__device__ __forceinline__ float quick_gelu(float u) { return u * sigmoidf_(RPO_QG * u); }
+__device__ __forceinline__ float quick_gelu(float u) { return u * qg_sigmoid(u); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
-  float s = sigmoidf_(RPO_QG * u);
-  return s * fmaf(RPO_QG * u, 1.0f - s, 1.0f);      // spelled out: the 224x384 kernel forms it inline from its own s
+  float s = qg_sigmoid(u);
+  return s * fmaf(RPO_QG * u, 1.0f - s, 1.0f);
+}
+// Four at a time, the full-rate part as packed fp32 (v_pk_mul_f32 / v_pk_add_f32): the epilogue of the 224x384 GEMM is
+// VALU-bound (per element two quarter-rate transcendentals + the rest; disassembly: hipcc left the scaling multiplies
+// and the +1 unpacked).  Same operations in the same order as quick_gelu, i.e. the same bits.
+__device__ __forceinline__ float4 quick_gelu4(float4 v) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  const f32x2_t za = a * RPO_QG_L2, zb = b * RPO_QG_L2;
+  f32x2_t ea = {__builtin_amdgcn_exp2f(za.x), __builtin_amdgcn_exp2f(za.y)};
+  f32x2_t eb = {__builtin_amdgcn_exp2f(zb.x), __builtin_amdgcn_exp2f(zb.y)};
+  ea = ea + 1.0f; eb = eb + 1.0f;
+  const f32x2_t ra = {__builtin_amdgcn_rcpf(ea.x), __builtin_amdgcn_rcpf(ea.y)};
+  const f32x2_t rb = {__builtin_amdgcn_rcpf(eb.x), __builtin_amdgcn_rcpf(eb.y)};
+  const f32x2_t oa = a * ra, ob = b * rb;
+  return make_float4(oa.x, oa.y, ob.x, ob.y);
 }
 
 // 16-byte store of a finished output tile.  RPO_NT_STORE (experiment, off): non-temporal, i.e. streamed past the L2's

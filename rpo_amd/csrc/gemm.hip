@@ -348,7 +348,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
               const int m = m0 + row, n = n0 + col;   // pre-activation of the back-propagated rows (few)
               if (p.aux != nullptr && m >= p.aux_row0 && m < p.M && n < p.N)
                 aux_store4<TAct>(p, (int64_t)(m - p.aux_row0) * p.ldaux + n, v);
-              v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+              v = quick_gelu4(v);
             }
             if constexpr (sizeof(TOut) == 2)
               *reinterpret_cast<uint2*>(smem + row * CROW + col * 2) =
@@ -435,7 +435,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           }
           if (IS_QG) {
             if (SAVE_U && ok[u] && m >= p.aux_row0) aux_store4<TAct>(p, (int64_t)(m - p.aux_row0) * p.ldaux + n, v);
-            v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+            v = quick_gelu4(v);
           }
           if (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_PATCH) {
             v.x += ex[u].x; v.y += ex[u].y; v.z += ex[u].z; v.w += ex[u].w;
