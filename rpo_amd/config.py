@@ -140,13 +140,18 @@ def act_dtype_for_prec(prec: str):
     "fp32": exact-f32 MFMA path (the parity mode).  "fp16" (the reference's GPU default: fp16 weights and
     activations, plain SGD, no loss scaling) -> native IEEE half storage: f16 weights / activations on
     v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Unlike the reference's fp16 mode the residual stream, LayerNorm,
-    softmax, logits, the prompts and the optimiser state stay fp32, so nothing here can underflow in the backward
-    and there is no loss scaling to reproduce.  "amp" (fp32 master weights + autocast + GradScaler) maps onto the
-    same storage mode: autocast's fp16 GEMMs with fp32 accumulate are what the f16 mode computes, its fp32 master
-    copy of the only trainable state is what the engine keeps anyway, and GradScaler's scale / unscale is the
-    identity on a gradient that is never stored in fp16; what is left of the scaler -- skipping a step whose gradient
-    holds Inf / NaN -- is `RPO(..., amp=True)` (rpo_sgd_step_guarded).  bf16 remains available as `torch.bfloat16` (same MFMA
-    rate, fp32 exponent range, 8 x the rounding error)."""
+    softmax, logits, the prompts, the prompt GRADIENTS and the optimiser state stay fp32, and there is no loss
+    scaling.  What IS stored in fp16 in the backward are the A operands of the dX GEMMs (the back-propagated row
+    gradients dx / du / dq and the two feature gradients the head writes): entries below 6e-5 go subnormal and below
+    6e-8 flush, exactly as in the reference's own fp16 run (plain SGD, no GradScaler: main_K24.yaml:35,
+    trainers/rpo.py:278 builds the scaler for "amp" only).  With the synthetic weights the row gradients are
+    1e-4 .. 1e-1 and the goldens bound the effect (gradients within 0.6 % of their largest entry); a user whose
+    gradients are much smaller should pick torch.bfloat16 (fp32 exponent range) -- no loss scale is applied for them.
+    "amp" (fp32 master weights + autocast + GradScaler) maps onto the same storage mode: autocast's fp16 GEMMs with
+    fp32 accumulate are what the f16 mode computes and its fp32 master copy of the only trainable state is what the
+    engine keeps anyway; of GradScaler only the skipping of a step whose gradient holds Inf / NaN is reproduced --
+    `RPO(..., amp=True)` (rpo_sgd_step_guarded) -- its scaling of small gradients is NOT.  bf16 remains available as
+    `torch.bfloat16` (same MFMA rate, fp32 exponent range, 8 x the rounding error)."""
     import torch
     table = {"fp32": torch.float32, "fp16": torch.float16, "amp": torch.float16}
     if prec not in table:

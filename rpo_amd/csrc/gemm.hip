@@ -882,6 +882,9 @@ int launch(const GemmParams& p, hipStream_t s) {
 #ifndef RPO_FILL_PCT
 #define RPO_FILL_PCT 80
 #endif
+#ifndef RPO_W4G_MOD
+#define RPO_W4G_MOD 256
+#endif
     const bool fills = tiles * 100 >= rounds * 256 * RPO_FILL_PCT;
     const bool ok = p.N % 8 == 0 && p.ldc % 8 == 0 && p.split_k == 1 && aligned16(p.C);
     // one-wave-per-SIMD kernel (gemm_w4.inc): 32-bit byte offsets inside the operand matrices, at least two 64-deep
@@ -897,7 +900,7 @@ int launch(const GemmParams& p, hipStream_t s) {
       const bool g_ok = w4_ok && w4g_plan(p, &gplan) != 0;
       const bool big_shape = p.force_cfg == 0 && p.M >= 2048 && p.N >= 1536;
       // ... or whole rounds of row-unit tiles (64 / 128 images: 2 / 4 rounds; 256x256 tiles would need 2.6 / 5.3)
-      if (g_ok && (p.force_cfg == 10 || (big_shape && (!fills || (gplan.from_units && gplan.tiles_m * gplan.tiles_n % 256 == 0)))))
+      if (g_ok && (p.force_cfg == 10 || (big_shape && (!fills || (gplan.from_units && gplan.tiles_m * gplan.tiles_n % RPO_W4G_MOD == 0)))))
         return launch_w4g<TOut, EPI>(p, s);
     }
     // a single round that fills at least 55 % of the CUs still favours the one-wave-per-SIMD kernel (K / V projection of

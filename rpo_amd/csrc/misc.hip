@@ -236,8 +236,11 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ 
   const bool lb_ok = lb64 >= 0 && lb64 < C;
   const int lb = lb_ok ? (int)lb64 : -1;
   const float inv = 1.0f / s;
+  // ... and so do this image's dl weights, hence both prompt gradients: rpo_sgd_step_guarded / check_finite then see the
+  // bad label instead of applying a finite-looking (softmax without its one-hot term) update
+  const float poison = lb_ok ? 0.0f : __builtin_nanf("");
   for (int c = threadIdx.x; c < C; c += 256)
-    dl[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul;
+    dl[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul + poison;
   if (threadIdx.x == 0) loss_b[b] = lb_ok ? (m + logf(s)) - z[lb] : __builtin_nanf("");
 }
 
@@ -298,7 +301,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int o = threadIdx.x; o < n_other; o += 256) {
       const int b = img ? g : o, c = img ? o : g;
       const float p = expf(logits[(int64_t)b * C + c] - smax[b]) * sinv[b];
-      wts[o] = (p - (label[b] == (int64_t)c ? 1.0f : 0.0f)) * gmul * other_inv[(int64_t)o * K + i];
+      const int64_t lb = label[b];
+      // an out-of-range label poisons the weights (hence both prompt gradients), not only the loss: the guarded
+      // optimiser step / check_finite must not apply a finite-looking update computed without the one-hot term
+      const float poison = lb >= 0 && lb < C ? 0.0f : __builtin_nanf("");
+      wts[o] = (p - (lb == (int64_t)c ? 1.0f : 0.0f)) * gmul * other_inv[(int64_t)o * K + i] + poison;
     }
   } else {
     if (loss != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // mean CE over the batch, fixed summation order

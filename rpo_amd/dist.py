@@ -35,8 +35,12 @@ class GradSync:
         # RPO_FORCE_DIST=1 runs the collective path even with one rank (exercises RCCL init / all-reduce /
         # barrier on a single-GPU box; the numbers are unchanged: sum over one rank, scale 1)
         self.enabled = self.world_size > 1 or os.environ.get("RPO_FORCE_DIST") == "1"
-        if torch.cuda.is_available() and torch.cuda.device_count() > self.local_rank:
-            torch.cuda.set_device(self.local_rank)              # every backend: kernels launch on the current device
+        # Only a distributed run moves the process-wide current device (to its local rank's GPU, for every backend:
+        # kernels launch on the current device).  A lone process keeps whatever device the caller chose -- a trainer
+        # built for cuda:1 must not be silently re-pointed at cuda:0.
+        self.in_launcher = "LOCAL_RANK" in os.environ
+        if (self.enabled or self.in_launcher) and torch.cuda.is_available() and torch.cuda.device_count() > self.local_rank:
+            torch.cuda.set_device(self.local_rank)
         if self.enabled and init and not dist.is_initialized():
             if backend is None:
                 backend = os.environ.get("RPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

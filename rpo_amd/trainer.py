@@ -10,6 +10,7 @@ single RCCL all-reduce of the flat gradient buffer sits between the two.
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 from dataclasses import dataclass
@@ -62,13 +63,17 @@ class RPO:
         # gradient holds Inf / NaN is skipped on every rank (the flag is computed after the all-reduce)
         self.amp = amp
         self.optim_cfg = optim or OptimConfig()
+        # default: joins (or creates) the process group when launched under torchrun; a lone process stays local.
+        # Built BEFORE the device is resolved: under a launcher it makes this rank's GPU the current device, and an
+        # index-less "cuda" then means that GPU on every rank (not cuda:0 eight times).
+        self.sync = sync or GradSync()
         self.device = torch.device(device)
         if self.device.index is None:
-            self.device = torch.device("cuda", torch.cuda.current_device())
+            idx = self.sync.local_rank if (self.sync.enabled and torch.cuda.device_count() > self.sync.local_rank) \
+                else torch.cuda.current_device()
+            self.device = torch.device("cuda", idx)
         self.batch_size = batch_size
         self.num_batches = num_batches
-        # default: joins (or creates) the process group when launched under torchrun; a lone process stays local
-        self.sync = sync or GradSync()
         self.use_graph = use_graph
         self.epoch = 0
         self.batch_idx = 0
@@ -243,8 +248,12 @@ class RPO:
         """What Dassl's `TrainerBase.save_model` -> `save_checkpoint` leaves on disk and the reference's reader
         (trainers/rpo.py:325-357) consumes: `state_dict` (the two prompt tensors), `epoch`, `optimizer`,
         `scheduler`, `val_result`; `is_best` also writes `model-best.pth.tar`, the file `load_model` opens by
-        default (:333).  The optimiser entry is torch.optim.SGD's own state-dict layout, so a reference run can
-        resume from it."""
+        default (:333).  Interoperable with the reference: `state_dict`, `epoch` and `optimizer` (torch.optim.SGD's own
+        state-dict layout).  NOT interoperable: `scheduler` -- Dassl's `resume_from_checkpoint` would
+        `load_state_dict` it into its warm-up wrapper, which only restores the wrapper's `last_epoch` (the successor
+        cosine restarts), so only {"last_epoch"} is written and a reference run should rebuild its scheduler from
+        `epoch`.  Dassl writes `model-best.pth.tar` alone when a validation result improves; `after_epoch_eval` here
+        also keeps the numbered file it is a copy of."""
         epoch = self.epoch if epoch is None else epoch
         ck = checkpoint_dict(self.model.prompt_learner.state_dict(), epoch, self.engine.mom, self.optim_cfg,
                              self.lr, self._steps, self.cfg.K * self.cfg.d_t, val_result)
@@ -267,8 +276,7 @@ class RPO:
         model_path = os.path.join(directory, "prompt_learner", model_file)
         if not os.path.exists(model_path):
             raise FileNotFoundError(f'Model not found at "{model_path}"')
-        # tensors, numbers and plain containers only (ours and Dassl's): no arbitrary unpickling
-        ck = torch.load(model_path, map_location="cpu", weights_only=True)
+        ck = load_checkpoint_file(model_path)
         sd = dict(ck["state_dict"])
         for k in ("token_prefix", "token_suffix"):              # :348-352
             sd.pop(k, None)
@@ -284,6 +292,81 @@ class RPO:
         self.engine.params_version += 1
         self.epoch = int(ck.get("epoch", 0))
         self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+
+
+# Names a checkpoint written by the reference's own run may reference (module, qualified name).  Dassl's
+# `save_checkpoint` pickles `scheduler.state_dict()`; with the yaml's WARMUP_EPOCH = 1 that is
+# ConstantWarmupScheduler's dict, whose `successor` entry IS a CosineAnnealingLR object holding the SGD optimiser
+# (defaultdict state, Parameters), so `weights_only=True` rejects every real reference checkpoint.
+_CKPT_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "Counter"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+    ("torch.optim.sgd", "SGD"), ("torch.optim.optimizer", "Optimizer"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+}
+_CKPT_ALLOWED_PREFIX = (("torch.optim.lr_scheduler", None),)      # every scheduler class of torch (plain data holders)
+
+
+class _Inert:
+    """Stand-in for classes of un-vendored packages (dassl.optim.lr_scheduler.*) met while unpickling a reference
+    checkpoint: takes any state, does nothing."""
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {})
+
+
+def load_checkpoint_file(path: str) -> dict:
+    """torch.load restricted to what a checkpoint needs.  First `weights_only=True` (tensors, numbers, plain containers:
+    every file this package writes).  A file written by the reference's own Dassl run holds the cosine scheduler object
+    and through it the optimiser (see _CKPT_ALLOWED), which torch's weights-only unpickler cannot rebuild even when
+    allow-listed (it refuses SETITEMS on the optimiser's defaultdict state); such files go through a restricted
+    `pickle.Unpickler` that resolves ONLY the names in _CKPT_ALLOWED, torch's storage types / dtypes and
+    torch.optim.lr_scheduler classes, maps `dassl.*` classes (un-vendored) to an inert stand-in and refuses everything
+    else -- no arbitrary callables.  Only `state_dict`, `epoch`, `optimizer` are read afterwards.
+    RPO_TRUST_CHECKPOINT=1: full unpickle for files holding anything else."""
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as err:
+        if os.environ.get("RPO_TRUST_CHECKPOINT") == "1":
+            return torch.load(path, map_location="cpu", weights_only=False)
+        first = err
+
+    class _U(pickle.Unpickler):
+        def find_class(self, module, name):
+            top = module.split(".")[0]
+            if top == "dassl":
+                return _Inert
+            key_mod = "builtins" if module == "__builtin__" else module        # protocol-2 spelling
+            ok = (key_mod, name) in _CKPT_ALLOWED or any(module == m for m, _ in _CKPT_ALLOWED_PREFIX)
+            if not ok and module == "torch":
+                obj = getattr(torch, name, None)
+                # dtypes and the legacy typed-storage classes torch.save names in persistent ids
+                ok = isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage"))
+            if not ok:
+                raise pickle.UnpicklingError(f"{module}.{name} is not allowed in a checkpoint")
+            return super().find_class(module, name)
+
+    class _P:                                      # the `pickle_module` protocol torch.load expects
+        __name__ = "rpo_amd_restricted_pickle"
+        Unpickler = _U
+        load = staticmethod(lambda f, **k: _U(f, **k).load())
+
+    try:
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_P)
+    except pickle.UnpicklingError as err:
+        raise pickle.UnpicklingError(
+            f"{path}: {err} (weights-only attempt: {str(first).splitlines()[-3] if str(first).count(chr(10)) > 2 else first}); "
+            "set RPO_TRUST_CHECKPOINT=1 to unpickle it fully if you trust the file") from err
 
 
 def checkpoint_dict(prompt_state, epoch: int, momentum: Optional[torch.Tensor], oc: OptimConfig, lr: float,

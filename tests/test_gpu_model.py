@@ -8,6 +8,7 @@ updated prompts and 1e-3 relative-to-max on gradients (measured ~1e-5).
 The bf16 throughput mode cannot meet 1e-3 at logit scale 100 (SURVEY.md section 7);
 it is asserted at a documented looser bound and its measured error is printed.
 """
+import functools
 import os
 
 import numpy as np
@@ -415,6 +416,84 @@ def test_full_size_properties(model, K, B, act):
 _F32_FULL = {}
 
 
+# Full-size fixtures (tools/make_golden_fullsize.py): the REAL reference run on the bench's own shapes (12 layers,
+# B = 32, every K of the configs[4] sweep), so that the model-level comparison goes through the kernels the bench
+# selects -- gemm_w4 / gemm_w4g / gemm_w4k at M = 32 x 221, the K = 48 path -- and not only through the generic tiles
+# that the small-batch goldens reach.  ViT-L/14 (configs[3]) cannot run in the reference (SURVEY.md finding 7); its
+# fixture comes from the dense oracle and is named oracle_*.
+FULL_GOLDEN = [("ref_full_k24_b32", "ViT-B/16", 24, 32), ("ref_full_k4_b32", "ViT-B/16", 4, 32),
+               ("ref_full_k8_b32", "ViT-B/16", 8, 32), ("ref_full_k16_b32", "ViT-B/16", 16, 32),
+               ("ref_full_k48_b32", "ViT-B/16", 48, 32), ("oracle_vitl14_k24_b16", "ViT-L/14", 24, 16)]
+FULL_TOL = {torch.float32: (TOL_F32, TOL_F32), torch.float16: (F16_LOGIT_ATOL, F16_GRAD_REL),
+            torch.bfloat16: (BF16_LOGIT_ATOL, BF16_GRAD_REL)}
+
+
+@functools.lru_cache(maxsize=2)
+def _full_workload(model, K, B):
+    from rpo_amd.config import vit_b16, vit_l14
+    cfg = (vit_b16 if model == "ViT-B/16" else vit_l14)(K=K)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    return cfg, sd, toks, tp, ip, synth.images(cfg, B), synth.labels(cfg, B)
+
+
+@pytest.mark.parametrize("act", [torch.float32, torch.float16, torch.bfloat16], ids=lambda v: str(v).replace("torch.", ""))
+@pytest.mark.parametrize("fixture,model,K,B", FULL_GOLDEN, ids=[f[0] for f in FULL_GOLDEN])
+def test_full_size_matches_reference_golden(fixture, model, K, B, act):
+    """Eval logits, train loss and both prompt gradients of the full-depth model at the bench's batch against the
+    reference's own outputs: f32 mode within the north star's 1e-3, f16 within 1e-2 (logits) / 0.6 % (gradients,
+    relative to the largest entry), bf16 within 0.12 / 5 %."""
+    from rpo_amd.custom_clip import CustomCLIP
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + ".npz")))
+    cfg, sd, toks, tp, ip, image, label = _full_workload(model, K, B)
+    assert np.array_equal(label, g["label"])
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=B, prompts=(tp, ip))
+    image, label = torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda()
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    m.prompt_learner.train()
+    loss = m(image, label)
+    loss.backward()
+    gt = m.prompt_learner.text_prompt.grad.cpu().numpy()
+    gi = m.prompt_learner.img_prompt.grad.cpu().numpy()
+    le, ll = np.abs(logits - g["logits"]).max(), abs(loss.item() - float(g["loss"]))
+    rt, ri = _relmax(gt, g["g_text"]), _relmax(gi, g["g_img"])
+    print(f"[full {fixture} {act}] logits err {le:.3e} loss err {ll:.3e} g_text rel {rt:.3e} g_img rel {ri:.3e}")
+    la, gr = FULL_TOL[act]
+    assert np.isfinite(logits).all() and le <= la and ll <= la
+    assert rt <= gr and ri <= gr
+    if act != torch.bfloat16:
+        assert (logits.argmax(-1) == g["logits"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("act,tol", [(torch.float32, TOL_F32), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)],
+                         ids=["float32", "float16", "bfloat16"])
+def test_full_size_sgd_steps_match_reference(act, tol):
+    """configs[1] through the trainer (graphs, fused SGD): the prompts after 1 and 2 optimiser steps at B = 32 against
+    the reference's torch.optim.SGD run with the same explicit hyper-parameters.  The prompts move by lr x gradient
+    ~ 1e-2 x 1e-1 per step, so the 16-bit modes' gradient error (0.3 % / 2.5 %) is far inside the bounds."""
+    from rpo_amd.trainer import RPO, OptimConfig
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_full_k24_b32.npz")))
+    cfg, sd, toks, tp, ip, _, _ = _full_workload("ViT-B/16", 24, 32)
+    lr, mom, wd = (float(v) for v in g["sgd_hparams"])
+    oc = OptimConfig(lr=lr, momentum=mom, weight_decay=wd, warmup_epoch=0, lr_scheduler="constant")
+    tr = RPO(cfg, sd, toks, oc, "cuda:0", act, batch_size=32, num_batches=10 ** 9, prompts=(tp, ip))
+    losses = []
+    for step in range(2):
+        batch = {"img": torch.from_numpy(synth.images(cfg, 32, seed=1234 + 10 * step)),
+                 "label": torch.from_numpy(synth.labels(cfg, 32, seed=4321 + 10 * step))}
+        losses.append(tr.forward_backward(batch)["loss"])
+        t = tr.model.prompt_learner.text_prompt.detach().cpu().numpy()
+        i = tr.model.prompt_learner.img_prompt.detach().cpu().numpy()
+        et = np.abs(t - g[f"text_prompt_step{step + 1}"]).max()
+        ei = np.abs(i - g[f"img_prompt_step{step + 1}"]).max()
+        print(f"[full sgd {act}] step {step + 1}: text prompt err {et:.2e} img prompt err {ei:.2e}")
+        assert et <= tol and ei <= tol
+    lt = {torch.float32: TOL_F32, torch.float16: F16_LOGIT_ATOL, torch.bfloat16: BF16_LOGIT_ATOL}[act]
+    assert np.abs(np.asarray(losses) - g["sgd_losses"]).max() <= lt
+
+
 def test_two_ranks_equal_one_rank_global_batch(tmp_path):
     """SURVEY.md section 8e's own correctness test on the HIP path: 2 ranks x B/2 images (both on this box's one GPU,
     gloo instead of RCCL, which refuses two ranks on one device) for two SGD steps must leave the prompts a 1-rank
@@ -542,6 +621,15 @@ def test_anomaly_scan_and_bad_labels():
     tr.detect_anomaly = False
     tr.engine.forward_backward(torch.from_numpy(image).cuda(), torch.tensor([0, 400], device="cuda"))
     assert torch.isnan(tr.engine.loss).all()
+    # ... and so are the prompt gradients (the softmax without its one-hot term would be a finite, wrong update): the
+    # guarded optimiser step then skips it and leaves the prompts untouched
+    assert torch.isnan(tr.engine.grads).any()
+    from rpo_amd import ops
+    before = tr.engine.params.clone()
+    found = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.sgd_step_guarded(tr.engine.params, tr.engine.grads, tr.engine.mom, 0.01, 0.9, 5e-4, 1.0, first_step=False,
+                         found_inf=found)
+    assert torch.equal(tr.engine.params, before) and int(found[0]) == 1
 
 
 @pytest.mark.gpu

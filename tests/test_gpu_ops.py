@@ -697,6 +697,7 @@ def test_head_fwd_bwd(B, C, K, e):
     bad = lab.clone(); bad[B // 2] = C
     o.head_fwd_bwd(i_f.to(dev()), t_f.to(dev()), bad.to(dev()), 100.0, logits, loss, d_i, d_t, ws)
     assert torch.isnan(loss).item()
+    assert torch.isnan(d_i).any() and torch.isnan(d_t).any()        # gradients poisoned too, not only the loss
     close(logits, lg, "f32", "head logits (bad label)", tol=5e-6)
 
 

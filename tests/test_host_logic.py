@@ -168,14 +168,83 @@ def test_checkpoint_writer_satisfies_the_reference_reader_contract(tmp_path):
 
 
 def test_committed_reference_checkpoint_fixture_layout():
-    """tests/golden/ckpt_d1_k4 (written by tools/make_golden.py from the reference's own modules) loads without
-    arbitrary unpickling and carries the keys the reader touches."""
+    """tests/golden/ckpt_d1_k4 (written by tools/make_golden.py from the reference's own modules) is in the layout a
+    real Dassl run leaves: its `scheduler` entry is the warm-up scheduler's state dict, which HOLDS the successor
+    CosineAnnealingLR object and through it the optimiser -- so torch's weights-only load refuses it, and the product's
+    restricted loader reads it (without arbitrary unpickling) and finds the keys the reader touches."""
+    import pickle
+    from rpo_amd.trainer import load_checkpoint_file
     d = os.path.join(ROOT, "tests", "golden", "ckpt_d1_k4", "prompt_learner")
     for name in ("model-best.pth.tar", "model.pth.tar-2"):
-        ck = torch.load(os.path.join(d, name), map_location="cpu", weights_only=True)
+        with pytest.raises(pickle.UnpicklingError):
+            torch.load(os.path.join(d, name), map_location="cpu", weights_only=True)
+        ck = load_checkpoint_file(os.path.join(d, name))
         assert ck["epoch"] == 2 and {"text_prompt", "img_prompt", "token_prefix", "token_suffix"} == set(ck["state_dict"])
+        succ = ck["scheduler"]["successor"]
+        assert type(succ) is torch.optim.lr_scheduler.CosineAnnealingLR and succ.T_max == 15
+        assert ck["scheduler"]["warmup_epoch"] == 1 and ck["scheduler"]["cons_lr"] == 1e-5
+        assert set(ck["optimizer"]["state"]) == {0, 1}
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_d1_k4.npz")))
     assert np.array_equal(ck["state_dict"]["text_prompt"].numpy(), g["text_prompt"])
+
+
+def test_checkpoint_loader_refuses_arbitrary_callables(tmp_path, monkeypatch):
+    """The restricted loader resolves an allow-list of names only: a pickle that reduces to os.system (or anything else
+    outside tensors / containers / torch's optimiser + scheduler classes) is refused; dassl.* classes (un-vendored)
+    become inert stand-ins; RPO_TRUST_CHECKPOINT=1 is the explicit opt-in to a full unpickle."""
+    import pickle
+    import sys
+    import types
+    from rpo_amd.trainer import load_checkpoint_file
+
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    f = str(tmp_path / "evil.pth")
+    torch.save({"state_dict": {}, "epoch": 1, "x": Evil()}, f)
+    monkeypatch.delenv("RPO_TRUST_CHECKPOINT", raising=False)
+    with pytest.raises(pickle.UnpicklingError, match="not allowed"):
+        load_checkpoint_file(f)
+    assert not marker.exists()
+    # a class from the un-vendored trainer engine inside the scheduler entry: inert stand-in, rest of the file intact
+    mod = types.ModuleType("dassl.optim.lr_scheduler")
+
+    class ConstantWarmupScheduler:
+        def __init__(self):
+            self.warmup_epoch = 1
+    ConstantWarmupScheduler.__module__ = "dassl.optim.lr_scheduler"
+    ConstantWarmupScheduler.__qualname__ = "ConstantWarmupScheduler"
+    mod.ConstantWarmupScheduler = ConstantWarmupScheduler
+    for name in ("dassl", "dassl.optim"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "dassl.optim.lr_scheduler", mod)
+    f2 = str(tmp_path / "dassl.pth")
+    torch.save({"state_dict": {"text_prompt": torch.ones(2, 3)}, "epoch": 4, "scheduler": ConstantWarmupScheduler()}, f2)
+    for name in ("dassl", "dassl.optim", "dassl.optim.lr_scheduler"):
+        monkeypatch.delitem(sys.modules, name)
+    ck = load_checkpoint_file(f2)
+    assert ck["epoch"] == 4 and torch.equal(ck["state_dict"]["text_prompt"], torch.ones(2, 3))
+    assert type(ck["scheduler"]).__name__ == "_Inert" and ck["scheduler"].warmup_epoch == 1
+
+
+def test_gradsync_leaves_the_current_device_alone_outside_a_launcher(monkeypatch):
+    """A lone process (no LOCAL_RANK, world size 1) must not have its current device moved by constructing GradSync
+    (the trainer builds one by default): only a distributed run pins the process to its local rank's GPU."""
+    from rpo_amd import dist as rdist
+    calls = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: calls.append(i))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RPO_FORCE_DIST", "RPO_ALL_RANKS_ON_GPU0"):
+        monkeypatch.delenv(k, raising=False)
+    s = rdist.GradSync(init=False)
+    assert not s.enabled and calls == []
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("LOCAL_RANK", "5")
+    s = rdist.GradSync(init=False)
+    assert s.enabled and calls == [5] and s.shard(256) == (160, 32)
 
 
 def test_config_from_state_dict_and_seeded_init_formula():

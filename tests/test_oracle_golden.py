@@ -53,6 +53,27 @@ def test_dense_oracle_matches_reference(tag):
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_dense_oracle_matches_reference_at_bench_size():
+    """The oracle against the reference's own output at the bench's shape (12 layers, K = 24, B = 32:
+    tools/make_golden_fullsize.py) -- it is also bench.py's cpu_baseline at exactly this size."""
+    import os
+    from helpers import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ref_full_k24_b32.npz")))
+    cfg = vit_b16(K=24)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    m = rpo_oracle.OracleRPO(sd, toks, cfg.K, cfg.patch)
+    m.set_prompts(tp, ip)
+    image, label = synth.images(cfg, 32), synth.labels(cfg, 32)
+    assert np.array_equal(label, g["label"])
+    out, gt, gi = m.loss_and_grads(image, label)
+    np.testing.assert_allclose(out.logits.detach().numpy(), g["logits"], atol=3e-5, rtol=0)
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-5
+    for mine, ref in ((gt.numpy(), g["g_text"]), (gi.numpy(), g["g_img"])):
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_prompt_rows_per_block():
     g = load_golden("d2_k8_b3")
     m, image, label = oracle_for("d2_k8_b3")

@@ -150,9 +150,10 @@ def main() -> None:
                    "source": "reference clip.tokenize (clip/clip.py:185-221) via tools/make_golden.py"}, f)
     print("G1 len_prompts", lens)
 
+    only = set(sys.argv[1:])                 # e.g. `make_golden.py ckpt` regenerates G7 / G8 alone
     manifest = {}
     # (tag, depth, K, B, logit_scale, extras)
-    cases = [
+    cases = [] if only and "cases" not in only else [
         ("d1_k4_b2", 1, 4, 2, np.log(100.0), dict(rows=False, sgd=False)),
         ("d2_k8_b3", 2, 8, 3, np.log(100.0), dict(rows=True, sgd=True)),
         ("d2_k24_b2_init", 2, 24, 2, np.log(1 / 0.07), dict(rows=False, sgd=False)),
@@ -241,8 +242,37 @@ def main() -> None:
     # CoOp-era checkpoints carry these two; the reader deletes them (trainers/rpo.py:348-352)
     state["token_prefix"] = torch.zeros(2, 1, cfg.d_t)
     state["token_suffix"] = torch.zeros(2, 3, cfg.d_t)
-    # Dassl's save_checkpoint (un-vendored) stores these five keys; the reader uses the first two
-    ck = {"state_dict": state, "epoch": 2, "optimizer": opt.state_dict(), "scheduler": None, "val_result": 12.5}
+    # Dassl's save_checkpoint (un-vendored) stores these five keys; the reader uses the first two.  `scheduler` is
+    # scheduler.state_dict() of what build_lr_scheduler returns for the yaml (WARMUP_EPOCH 1, constant): Dassl's
+    # ConstantWarmupScheduler wrapping CosineAnnealingLR.  LRScheduler.state_dict() is every attribute but the
+    # optimiser, so it HOLDS the successor CosineAnnealingLR object (and through it the SGD optimiser): a real
+    # reference checkpoint is not a tensors-only pickle.  The wrapper is re-created from its published semantics
+    # (tests/test_host_logic.py does the same); only its state dict is stored, not the class.
+    class ConstantWarmupScheduler(torch.optim.lr_scheduler.LRScheduler):
+        def __init__(self, optimizer, successor, warmup_epoch, cons_lr):
+            self.successor, self.warmup_epoch, self.cons_lr = successor, warmup_epoch, cons_lr
+            super().__init__(optimizer)
+
+        def get_lr(self):
+            if self.last_epoch >= self.warmup_epoch:
+                return self.successor.get_last_lr()
+            return [self.cons_lr for _ in self.base_lrs]
+
+        def step(self, epoch=None):
+            if self.last_epoch >= self.warmup_epoch:
+                self.successor.step(epoch)
+                self._last_lr = self.successor.get_last_lr()
+            else:
+                super().step(epoch)
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        succ = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=15)
+        sched = ConstantWarmupScheduler(opt, succ, 1, 1e-5)
+        sched.step(); sched.step()                                        # two epochs done
+    ck = {"state_dict": state, "epoch": 2, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(),
+          "val_result": 12.5}
     torch.save(ck, os.path.join(ck_dir, "model.pth.tar-2"))
     torch.save(ck, os.path.join(ck_dir, "model-best.pth.tar"))
     np.savez_compressed(os.path.join(out_dir, "ref_ckpt_d1_k4.npz"),
@@ -251,6 +281,8 @@ def main() -> None:
                         momentum_img=opt.state_dict()["state"][1]["momentum_buffer"].numpy())
     print("G8 checkpoint written", ck_dir)
 
+    if only and "cases" not in only:
+        return
     with open(os.path.join(out_dir, "manifest.json"), "w") as f:
         json.dump(dict(generator="tools/make_golden.py", torch=torch.__version__,
                        numpy=np.__version__, cases=manifest), f, indent=1)
