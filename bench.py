@@ -317,10 +317,37 @@ def committed_step_traffic(args):
     files = sorted(glob.glob(os.path.join(here, "profiles", "r*_step_hbm_traffic.txt")))
     if not files:
         return None, None
+    # A counter summary describes the kernels it was collected with: if any kernel source changed after the summary was
+    # written, the number is stale and is NOT attached (git checkouts give every file the checkout time, so sources
+    # are compared through the hash the summary records, when it records one, and through mtimes otherwise)
+    src_dir = os.path.join(here, "rpo_amd", "csrc")
+    want = None
+    for line in open(files[-1]):
+        if line.startswith("kernel_sources_sha1"):
+            want = line.split()[1]
+    if want is not None:
+        if want != kernel_sources_sha1():
+            return None, f"{os.path.relpath(files[-1], here)} is stale (kernel sources changed since it was collected)"
+    else:
+        newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+        if newest > os.path.getmtime(files[-1]) + 1.0:
+            return None, f"{os.path.relpath(files[-1], here)} is older than rpo_amd/csrc: not attached"
     for line in open(files[-1]):
         if line.startswith("traffic_bytes_per_step"):
             return float(line.split()[1]), os.path.relpath(files[-1], here)
     return None, None
+
+
+def kernel_sources_sha1() -> str:
+    """Fingerprint of rpo_amd/csrc (what tools/summarize_profiles.py records next to a counter summary)."""
+    import hashlib
+    src_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rpo_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(src_dir)):
+        h.update(f.encode())
+        with open(os.path.join(src_dir, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def self_launch(n: int) -> int:
@@ -368,11 +395,28 @@ def main() -> None:
     cfg = (vit_b16 if args.model == "ViT-B/16" else vit_l14)(K=args.K)
     toks = synth.default_tokens(cfg)
     lens = synth.len_prompts(toks)
-    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    token_rows = np.unique(toks).tolist() + [49407]
+    shared = None
+    if sync.world_size > 1:
+        # ONE generation of the 150 M synthetic weights per node (local rank 0; the others memory-map its file) instead
+        # of one numpy RNG pass per rank -- eight of them on one host's cores is most of the start-up time of an N = 8 run
+        import tempfile
+        shared = os.path.join(tempfile.gettempdir(), f"rpo_amd_weights_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.npy")
+        sd = synth.clip_state_dict_shared(cfg, 0, token_rows, shared, writer=sync.local_writer, barrier=sync.barrier)
+    else:
+        sd = synth.clip_state_dict(cfg, seed=0, token_rows=token_rows)
     prompts = synth.prompts(cfg, sd, seed=7)
     act = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     tr = RPO(cfg, sd, toks, OptimConfig(), dev, act, batch_size=args.batch, num_batches=10 ** 9,
              use_graph=not args.no_graph, sync=sync, prompts=prompts)
+    if shared is not None:
+        sync.barrier()                                   # every rank has packed its weights into HBM
+        if sync.local_writer:
+            for fn in (shared, shared + ".json"):
+                try:
+                    os.remove(fn)
+                except OSError:
+                    pass
 
     # synthetic batches resident in HBM before the timed region (distinct data per rank and step)
     pool = 4
@@ -392,6 +436,18 @@ def main() -> None:
     dt_local = time.perf_counter() - t0
     dt = sync.max_over_ranks(dt_local, dev)
     last_loss = float(loss.item())
+    coll_us = None
+    if sync.enabled:
+        # the step's only collective on its own: the flat prompt-gradient buffer, back to back on the step's stream
+        g = tr.engine.grads.clone()
+        for _ in range(5):
+            sync.all_reduce_sum(g)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            sync.all_reduce_sum(g)
+        torch.cuda.synchronize()
+        coll_us = sync.max_over_ranks(1e6 * (time.perf_counter() - t1) / 50, dev)
 
     global_batch = args.batch * sync.world_size
     ms = 1e3 * dt / args.steps
@@ -411,16 +467,20 @@ def main() -> None:
                                f"n_cls={cfg.n_cls} (Oxford-Pets base prompts), full train step (fwd+bwd+SGD)",
                    "global_batch": global_batch, "parallelism": f"dp{sync.world_size}",
                    "collective": sync.describe(),
+                   "collective_us": None if coll_us is None else round(coll_us, 1),
+                   "collective_bytes": int(tr.engine.grads.numel() * 4) if sync.enabled else 0,
                    "hip_graph": not args.no_graph, "final_loss": round(last_loss, 5)},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma",
+                     # the stricter figure first: FLOPs the engine really EXECUTES per step (the SURVEY 8d contract
+                     # figure below also counts the last block's frozen-row q / attention / out-proj / MLP work, which
+                     # is dead -- only its prompt rows are consumed -- and skipped)
+                     "frac_executed": round(fl_exec / (dt / args.steps) / 1e12 / peak, 4),
+                     "achieved_executed": round(fl_exec / (dt / args.steps) / 1e12, 2),
+                     "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/step/GPU",
                      "traffic_source": traffic_src,
                      "algorithmic_gflop_per_step_per_gpu": round(fl_step / 1e9, 2),
-                     # the contract figure above counts the last block's frozen rows in full; the engine skips their
-                     # dead q / attention / out-proj / MLP work, so it EXECUTES less than it is credited with:
-                     "executed_gflop_per_step_per_gpu": round(fl_exec / 1e9, 2),
-                     "achieved_executed": round(fl_exec / (dt / args.steps) / 1e12, 2),
-                     "frac_executed": round(fl_exec / (dt / args.steps) / 1e12 / peak, 4),
                      "gflop_per_image": round(sum(flops_image(cfg)) / 1e9, 2),
                      "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2)},
     }
@@ -451,7 +511,17 @@ def main() -> None:
         if args.dtype != "f32" and sync.world_size == 1 and not args.no_precision:
             del tr
             torch.cuda.empty_cache()
-            out["precision"] = precision_report(cfg, sd, toks, prompts, dev, min(args.batch, 8))
+            pr = out["precision"] = precision_report(cfg, sd, toks, prompts, dev, min(args.batch, 8))
+            # which storage mode meets which bound on logits (north star: 1e-3 of the CPU reference in fp32).  The f32
+            # mode is held to 1e-3 against the reference's own outputs by tests/ (small and full-size goldens); the
+            # 16-bit modes are measured here against that f32 mode on one batch.
+            met = lambda e: next((b for b in (1e-3, 1e-2, 0.12) if e <= b), None)
+            out["tolerance_met"] = {
+                "f32": 1e-3,
+                "f16": met(pr["f16"]["logits_max_abs_err"]), "bf16": met(pr["bf16"]["logits_max_abs_err"]),
+                "timed_mode": args.dtype,
+                "note": "smallest of (1e-3, 1e-2, 0.12) that bounds the max abs logits error; the north star's 1e-3 is met "
+                        "by the f32 mode only -- the timed mode's own error is `precision`"}
         if sync.world_size == 1 and not args.no_cpu_baseline:
             full = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
             out["cpu_baseline"] = cpu_baseline(cfg, full, toks, prompts)

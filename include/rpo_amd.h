@@ -229,6 +229,16 @@ int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, const void* vc
                       const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
                       const int32_t* len, int n_cls, int rows, int Lmax, int H, float scale, void* stream);
 
+/* Dense backward of the text tower's causal attention: dq, dk, dv for ALL rows of every class (q, k, v, their
+ * gradients: [n_cls * Lmax, ld / ldd], class c = rows c*Lmax .. c*Lmax + len[c]; row t reads keys [0, min(t + 1, len[c]))
+ * as rpo_text_attn_fwd with causal = 1), given d_out = dL/d(attention output).  Replaces autograd of
+ * nn.MultiheadAttention's SDPA (clip/model.py:186) under CLIP's plain causal mask (:332-338) for the sibling trainers
+ * whose learned parameters sit in front of the class name (CoOp, trainers/coop.py:117-134,258-281).  Rows >= len[c]
+ * get zero gradients.  Lmax <= 80 (CLIP's context is 77). */
+int rpo_text_attn_bwd_dense(const void* q, const void* k, const void* v, int64_t ld, const void* d_out, int64_t lddo,
+                            void* dq, void* dk, void* dv, int64_t ldd, int dtype, const int32_t* len, int n_cls,
+                            int Lmax, int H, float scale, void* stream);
+
 /* Cosine-logit head, cross-entropy and their backward (trainers/rpo.py:215-230):
  *   logits[b,c] = (scale_exp / K) * sum_i <img_f[b,i]/|.|, text_f[c,i]/|.|>
  *   loss = mean_b CE(logits[b], label[b])

@@ -1,0 +1,132 @@
+"""CoOp on the HIP engine: the host-side mirror of `trainers/coop.py` (PromptLearner :60-134, CustomCLIP :185-208, the
+`CoOp` trainer's `forward_backward` :258-281) -- SURVEY.md section 8f rank 4, the sibling trainer that shares RPO's towers
+without the read-only mask.
+
+    prompts  = [SOS | ctx (n_ctx learned vectors, shared by all classes) | class name . EOT]      (:117-134, "end")
+    logits   = exp(logit_scale) * normalise(encode_image(image)) @ normalise(encode_text(prompts)).T
+    loss     = F.cross_entropy(logits, label);   only `ctx` is trained (:228-230)
+
+Unlike RPO's prompts, a context vector is read by every later token, so its gradient needs the DENSE text-tower backward
+(all tokens of all classes, causal attention with dK / dV): `Engine.coop_forward_backward`.  The image tower is plain
+frozen CLIP and is only run forward.  Generic context (CSC = False) and class token at the end -- the reference's own
+defaults (configs/trainers/CoOp/vit_b16_ep50.yaml) -- are what is built; "middle" / "front" raise in the reference
+config used here as well (its code path for them exists but is not exercised by the repo's scripts).
+
+The caller provides the token ids of the "X X .. name." prompts (the BPE tokenizer is out of scope).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import RPOConfig
+from .custom_clip import config_from_state_dict
+from .engine import Engine
+from .trainer import OptimConfig, lr_at_epoch
+
+
+class CoOpPromptLearner:
+    """State of `trainers/coop.py:PromptLearner`: `ctx` [n_ctx, d_t] lives in the engine (fp32 master copy on the device);
+    `token_prefix` / `token_suffix` are the embeddings of SOS and of "name . EOT ..." that the reference registers as
+    buffers (:100-101) and that its checkpoints therefore contain."""
+
+    def __init__(self, engine: Engine, n_ctx: int, token_embedding: np.ndarray, tokens: np.ndarray):
+        self.engine, self.n_ctx = engine, n_ctx
+        emb = np.asarray(token_embedding)[np.asarray(tokens)]                       # [n_cls, 77, d_t]
+        self.token_prefix = torch.from_numpy(np.ascontiguousarray(emb[:, :1]))
+        self.token_suffix = torch.from_numpy(np.ascontiguousarray(emb[:, 1 + n_ctx:]))
+        self.training = True
+
+    @property
+    def ctx(self) -> torch.Tensor:
+        return self.engine.coop_ctx
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {"ctx": self.ctx.detach().cpu().clone(), "token_prefix": self.token_prefix.clone(),
+                "token_suffix": self.token_suffix.clone()}
+
+
+class CoOpCustomCLIP:
+    """`trainers/coop.py:CustomCLIP`: `model(image)` -> logits [B, n_cls] (fp32, on the device)."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int,
+                 device: str | torch.device = "cuda:0", act_dtype: torch.dtype = torch.float16, max_batch: int = 32,
+                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None):
+        tokens = np.asarray(tokenized_prompts, dtype=np.int64)
+        if cfg is None:
+            cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])     # one (unused) RPO prompt row per image
+        self.cfg = cfg
+        self.engine = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        with torch.cuda.device(self.engine.dev):
+            self.engine.coop_setup(n_ctx)
+            if ctx is None:
+                # "Initializing a generic context": nn.init.normal_(ctx_vectors, std=0.02) from torch's global generator
+                # (trainers/coop.py:87-88) -- the same draw, so a seeded run starts from the reference's vectors
+                ctx = torch.empty(n_ctx, cfg.d_t).normal_(std=0.02).numpy()
+            self.engine.coop_ctx.copy_(torch.as_tensor(np.asarray(ctx, dtype=np.float32)))
+        self.prompt_learner = CoOpPromptLearner(self.engine, n_ctx, state_dict["token_embedding.weight"], tokens)
+        self.tokenized_prompts = tokens
+
+    def __call__(self, image: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        with torch.cuda.device(eng.dev):
+            image = image.to(device=eng.dev, dtype=torch.float32).contiguous()
+            return eng.coop_forward_backward(image, None)
+
+
+class CoOp:
+    """The trainer's step (trainers/coop.py:258-281): forward -> cross-entropy -> zero_grad -> backward -> SGD step on
+    `ctx`, returning {"loss", "acc"}; per-epoch LR update.  Optimiser hyper-parameters as for RPO (Dassl defaults are
+    un-vendored, hence explicit: OptimConfig)."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int = 16,
+                 optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
+                 act_dtype: torch.dtype = torch.float16, batch_size: int = 32, num_batches: int = 1,
+                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None):
+        self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=50)       # configs/trainers/CoOp/vit_b16_ep50.yaml
+        self.model = CoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, cfg)
+        self.engine, self.cfg = self.model.engine, self.model.cfg
+        self.device = self.engine.dev
+        self.batch_size, self.num_batches = batch_size, num_batches
+        self.epoch = self.batch_idx = self._steps = 0
+        self.lr = lr_at_epoch(self.optim_cfg, 0)
+
+    def parse_batch_train(self, batch):
+        img = batch["img"].to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        label = torch.as_tensor(batch["label"])
+        if not label.is_cuda:
+            lo, hi = int(label.min()), int(label.max())
+            if lo < 0 or hi >= self.cfg.n_cls:
+                raise IndexError(f"Target {hi if hi >= self.cfg.n_cls else lo} is out of bounds (n_cls = {self.cfg.n_cls})")
+        return img, label.to(self.device, dtype=torch.int64, non_blocking=True)
+
+    def forward_backward(self, batch) -> Dict[str, float]:
+        eng, oc = self.engine, self.optim_cfg
+        with torch.cuda.device(self.device):
+            image, label = self.parse_batch_train(batch)
+            logits = eng.coop_forward_backward(image, label)
+            ops.sgd_step(eng.coop_ctx.view(-1), eng.coop_grad.view(-1), eng.coop_mom.view(-1), self.lr, oc.momentum,
+                         oc.weight_decay, 1.0, first_step=(self._steps == 0))
+            self._steps += 1
+            acc = float((logits.argmax(1) == label).float().mean().item()) * 100.0      # compute_accuracy()[0]
+            summary = {"loss": float(eng.loss.item()), "acc": acc}
+        if (self.batch_idx + 1) == self.num_batches:
+            self.epoch += 1
+            self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+            self.batch_idx = 0
+        else:
+            self.batch_idx += 1
+        return summary
+
+    @torch.no_grad()
+    def model_inference(self, image: torch.Tensor) -> torch.Tensor:
+        return self.model(image)

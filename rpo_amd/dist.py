@@ -55,6 +55,14 @@ class GradSync:
                                "GradSync() (init=True) or call torch.distributed.init_process_group first")
 
     @property
+    def local_writer(self) -> bool:
+        """True on the one rank per node that prepares node-shared files (local rank 0; with every rank forced onto
+        GPU 0 by the test hook, global rank 0)."""
+        if os.environ.get("RPO_ALL_RANKS_ON_GPU0") == "1":
+            return self.rank == 0
+        return int(os.environ.get("LOCAL_RANK", "0")) == 0
+
+    @property
     def grad_scale(self) -> float:
         return 1.0 / self.world_size
 

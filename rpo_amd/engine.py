@@ -545,6 +545,122 @@ class Engine:
                          self.logits[:B], None, None, None, self.head_ws)
         return self.logits[:B]
 
+    # ------------------------------------------------------------------ CoOp: training the context vectors
+    def coop_setup(self, n_ctx: int) -> None:
+        """Buffers of the sibling trainer CoOp (trainers/coop.py): the learned context `coop_ctx` [n_ctx, d_t] (fp32
+        master copy, gradient, momentum) and, per text block, everything the DENSE text-tower backward re-reads -- the
+        gradient of a context vector flows through every token of every class (plain causal mask), unlike RPO's prompts.
+        n_cls * Lmax rows (a few hundred), so this is small."""
+        cfg, dev, act = self.cfg, self.dev, self.act
+        n, L, dt, e = cfg.n_cls, self.Lmax, cfg.d_t, cfg.embed
+        assert 1 + n_ctx < self.Lmax and self.Lmax <= 80, "tokens must be the ids of the 'X X .. name.' prompts"
+        Rf = n * L
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        a = lambda *s: torch.empty(*s, dtype=act, device=dev)
+        au = f32 if act == torch.float32 else a
+        Lt = cfg.layers_t
+        self.coop_n_ctx = n_ctx
+        self.coop_ctx = torch.zeros(n_ctx, dt, dtype=torch.float32, device=dev)
+        self.coop_grad = torch.zeros(n_ctx, dt, dtype=torch.float32, device=dev)
+        self.coop_mom = torch.zeros(n_ctx, dt, dtype=torch.float32, device=dev)
+        self.cx = [f32(Rf, dt) for _ in range(Lt + 1)]
+        self.cxm = [f32(Rf, dt) for _ in range(Lt)]
+        self.cqkv = [a(Rf, 3 * dt) for _ in range(Lt)]
+        self.cu = [au(Rf, 4 * dt) for _ in range(Lt)]
+        self.ch, self.catt, self.cg = a(Rf, dt), a(Rf, dt), a(Rf, 4 * dt)
+        self.c_dxa, self.c_dxb = f32(Rf, dt), f32(Rf, dt)
+        self.c_dxc, self.c_da = a(Rf, dt), a(Rf, dt)
+        self.c_du, self.c_dqkv = a(Rf, 4 * dt), a(Rf, 3 * dt)
+        self.c_dy = f32(max(SPLIT_FC, SPLIT_Q), Rf, dt)
+        self.c_eot = torch.arange(n, device=dev) * L + (self.len_i32.to(torch.int64) - 1)       # EOT row of every class
+        self.c_x_eot, self.c_dx_eot, self.c_dy_eot = f32(n, dt), f32(n, dt), f32(n, dt)
+        self.c_y_eot = a(n, dt)
+        self.c_text_f, self.c_d_text_f = f32(n, e), f32(n, e)
+        self.c_d_text_f_a = a(n, e)
+        self.c_d_img_f = f32(self.max_batch, e)
+        self.c_ctx_rows = f32(n * n_ctx, dt)
+        if self.img_cls_f is None:
+            self.img_cls_f = torch.empty(self.max_batch, e, dtype=torch.float32, device=dev)
+        # dX of the packed in-projection needs the whole W_in transposed ([d, 3d]); RPO's backward only its q third
+        self.c_w_in_t = [blk.w_in.t().contiguous() for blk in self.txt]
+
+    def _coop_text_forward(self, train: bool) -> None:
+        """TextEncoder.forward of trainers/coop.py:47-58 on prompts = [SOS | ctx | class name . EOT] (:117-134): all
+        tokens up to the longest EOT, plain causal mask, every block's inputs kept for the backward."""
+        cfg = self.cfg
+        n, L, dt, H, nc = cfg.n_cls, self.Lmax, cfg.d_t, cfg.heads_t, self.coop_n_ctx
+        Rf = n * L
+        x0 = self.cx[0]
+        x0.copy_(self.text_x_frozen)
+        x0.view(n, L, dt)[:, 1:1 + nc] = (self.coop_ctx + self.text_pos[1:1 + nc])[None]
+        for l, blk in enumerate(self.txt):
+            x, xm, qkv = self.cx[l], self.cxm[l], self.cqkv[l]
+            ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, self.ch)
+            ops.gemm_nt(self.ch, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in)
+            ops.text_attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], self.catt, self.len_i32, n, L, L, H,
+                              causal=True, scale=SCALE)
+            ops.gemm_nt(self.catt, blk.w_out, xm, EPI_BIAS_RESID, bias=blk.b_out, resid=x)
+            ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, self.ch)
+            ops.gemm_nt(self.ch, blk.w_fc, self.cg, EPI_BIAS_QGELU, bias=blk.b_fc, aux=self.cu[l] if train else None,
+                        aux_row0=0 if train else Rf)
+            ops.gemm_nt(self.cg, blk.w_proj, self.cx[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
+        torch.index_select(self.cx[-1], 0, self.c_eot, out=self.c_x_eot)                  # feature at the EOT token
+        ops.layernorm_fwd(self.c_x_eot, self.ln_final[0], self.ln_final[1], self.c_y_eot)
+        ops.gemm_nt(self.c_y_eot, self.text_proj_t, self.c_text_f, EPI_NONE)
+
+    def _coop_text_backward(self) -> None:
+        """d loss / d ctx: autograd of the whole text tower for all tokens (dX GEMMs only -- the weights are frozen), the
+        causal attention backward with dK / dV (rpo_text_attn_bwd_dense), then the rows of the context positions summed
+        over the classes (ctx.unsqueeze(0).expand, trainers/coop.py:119-121)."""
+        cfg = self.cfg
+        n, L, dt, H, nc = cfg.n_cls, self.Lmax, cfg.d_t, cfg.heads_t, self.coop_n_ctx
+        f32m = self.act == torch.float32
+        dxa, dxb, dxc, dy = self.c_dxa, self.c_dxb, self.c_dxc, self.c_dy
+        ops.gemm_nt(self.c_d_text_f if f32m else self.c_d_text_f_a, self.text_proj, self.c_dy_eot, EPI_NONE)
+        ops.layernorm_bwd(self.c_dy_eot, self.c_x_eot, self.ln_final[0], None, self.c_dx_eot)
+        dxa.zero_()
+        dxa.index_copy_(0, self.c_eot, self.c_dx_eot)
+        if not f32m:
+            ops.convert(dxa, dxc)
+        for l in reversed(range(len(self.txt))):
+            blk, qkv = self.txt[l], self.cqkv[l]
+            ops.gemm_nt(dxa if f32m else dxc, blk.w_proj_t, self.c_du, EPI_QGELU_BWD, aux=self.cu[l])
+            ops.gemm_nt(self.c_du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC)
+            ops.layernorm_bwd(dy[:SPLIT_FC], self.cxm[l], blk.ln2_w, dxa, dxb, None if f32m else dxc)
+            ops.gemm_nt(dxb if f32m else dxc, blk.w_out_t, self.c_da, EPI_NONE)
+            dq = self.c_dqkv
+            ops.text_attn_bwd_dense(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], self.c_da, dq[:, :dt],
+                                    dq[:, dt:2 * dt], dq[:, 2 * dt:], self.len_i32, n, L, H, SCALE)
+            ops.gemm_nt(dq, self.c_w_in_t[l], dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)
+            ops.layernorm_bwd(dy[:SPLIT_Q], self.cx[l], blk.ln1_w, dxb, dxa, None if f32m else dxc)
+        self.c_ctx_rows.view(n, nc, dt).copy_(dxa.view(n, L, dt)[:, 1:1 + nc])
+        # reduce_groups sums `groups` consecutive blocks of `rows` rows: classes are the groups
+        ops.reduce_groups(self.c_ctx_rows, self.coop_grad, n)
+
+    def coop_forward_backward(self, image: torch.Tensor, label: Optional[torch.Tensor]) -> torch.Tensor:
+        """trainers/coop.py:196-208 + :266-270: logits = exp(logit_scale) * normalise(image features of the plain image
+        tower) @ normalise(text features of [SOS | ctx | name . EOT])^T; with `label`, also the mean cross-entropy
+        (self.loss) and d loss / d ctx (self.coop_grad).  Returns self.logits[:B]."""
+        cfg = self.cfg
+        B = image.shape[0]
+        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and B <= self.max_batch
+        assert image.device == self.dev and torch.cuda.current_device() == self.dev.index
+        N, dv, e, n = cfg.n_frozen, cfg.d_v, cfg.embed, cfg.n_cls
+        train = label is not None
+        self._coop_text_forward(train)
+        self._image_forward(image, train=False, full_last=True)
+        cls_rows = self.x[-1][:B * N].view(B, N, dv)[:, 0, :]
+        ops.layernorm_fwd(cls_rows, self.ln_post[0], self.ln_post[1], self.y_post[:B])
+        ops.gemm_nt(self.y_post[:B], self.img_proj_t, self.img_cls_f[:B], EPI_NONE)
+        extra = {} if (not train or self.act == torch.float32) else dict(d_text_f_act=self.c_d_text_f_a)
+        ops.head_fwd_bwd(self.img_cls_f[:B].view(B, 1, e), self.c_text_f.view(n, 1, e), label, self.logit_scale_exp,
+                         self.logits[:B], self.loss if train else None,
+                         self.c_d_img_f[:B].view(B, 1, e) if train else None,
+                         self.c_d_text_f.view(n, 1, e) if train else None, self.head_ws, **extra)
+        if train:
+            self._coop_text_backward()
+        return self.logits[:B]
+
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
         """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in
         self.loss, self.logits, self.grads (= [g_text | g_img]).  Capturable in a HIP graph."""

@@ -205,6 +205,17 @@ def text_attn_fwd(q, kc, vc, out, len_i32, n_cls: int, rows: int, Lmax: int, H: 
     return out
 
 
+def text_attn_bwd_dense(q, k, v, d_out, dq, dk, dv, len_i32, n_cls: int, Lmax: int, H: int, scale: float = 0.125):
+    """dq, dk, dv of the causal text attention for every row (include/rpo_amd.h: rpo_text_attn_bwd_dense)."""
+    assert _ld(q) == _ld(k) == _ld(v) and _ld(dq) == _ld(dk) == _ld(dv) and len_i32.dtype == torch.int32
+    assert q.dtype == d_out.dtype == dq.dtype
+    check(_lib.load().rpo_text_attn_bwd_dense(q.data_ptr(), k.data_ptr(), v.data_ptr(), _ld(q), d_out.data_ptr(),
+                                              _ld(d_out), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _ld(dq),
+                                              dtype_code(q.dtype), len_i32.data_ptr(), n_cls, Lmax, H, scale, _stream()),
+          "rpo_text_attn_bwd_dense")
+    return dq
+
+
 def text_attn_bwd(q, kc, vc, da, dq, len_i32, n_cls: int, rows: int, Lmax: int, H: int, scale: float = 0.125):
     assert _ld(kc) == _ld(vc) and len_i32.dtype == torch.int32
     check(_lib.load().rpo_text_attn_bwd(q.data_ptr(), _ld(q), kc.data_ptr(), vc.data_ptr(), _ld(kc),

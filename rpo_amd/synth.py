@@ -122,6 +122,39 @@ def clip_state_dict(cfg: RPOConfig, seed: int = 0, token_rows: Iterable[int] | N
     return sd
 
 
+def clip_state_dict_shared(cfg: RPOConfig, seed: int, token_rows, path: str, writer: bool, barrier) -> Dict[str, np.ndarray]:
+    """One generation per NODE instead of one per rank: the local writer rank generates the state dict and leaves it in
+    `path` as one flat fp32 file + a JSON index (written to a temporary name and renamed, so a reader never sees a
+    partial file), `barrier()` is called by every rank, and the other ranks memory-map it read-only (page cache: one
+    physical copy for the node).  Bit-identical to clip_state_dict on every rank by construction.  The writer removes
+    nothing: the caller owns `path` (bench.py deletes it after the engines are built)."""
+    idx_path = path + ".json"
+    if writer:
+        sd = clip_state_dict(cfg, seed=seed, token_rows=token_rows)
+        index, off = {}, 0
+        for k in sorted(sd):
+            a = np.asarray(sd[k])                       # (ascontiguousarray would turn the 0-d logit_scale into [1])
+            index[k] = [off, list(a.shape)]
+            off += a.size
+        flat = np.lib.format.open_memmap(path + ".tmp", mode="w+", dtype=np.float32, shape=(off,))
+        for k, (o, shape) in index.items():
+            flat[o:o + int(np.prod(shape, dtype=np.int64))] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
+        flat.flush()
+        del flat
+        with open(idx_path + ".tmp", "w") as f:
+            json.dump(index, f)
+        os.replace(path + ".tmp", path)
+        os.replace(idx_path + ".tmp", idx_path)
+        barrier()
+        return sd
+    barrier()
+    with open(idx_path) as f:
+        index = json.load(f)
+    flat = np.load(path, mmap_mode="r")
+    return {k: (flat[o:o + int(np.prod(shape, dtype=np.int64))].reshape(tuple(shape)) if shape else np.array(flat[o], dtype=np.float32))
+            for k, (o, shape) in index.items()}
+
+
 def state_dict_checksum(sd: Dict[str, np.ndarray]) -> str:
     """Order-independent fingerprint used by fixtures to detect generator drift."""
     h = 0

@@ -29,7 +29,12 @@ def _worker(rank, world, port, out_dir):
     assert sync.world_size == world and sync.rank == rank and sync.enabled
     cfg = vit_b16(layers_v=1, layers_t=1, K=4)
     toks = synth.oxford_pets_base_tokens()
-    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    # one weight generation per node (bench.py's N > 1 path): local rank 0 writes, the other rank memory-maps
+    rows = np.unique(toks).tolist() + [49407]
+    sd = synth.clip_state_dict_shared(cfg, 0, rows, os.path.join(out_dir, "weights.npy"), writer=sync.local_writer,
+                                      barrier=sync.barrier)
+    assert sync.local_writer == (rank == 0)
+    assert synth.state_dict_checksum(sd) == synth.state_dict_checksum(synth.clip_state_dict(cfg, seed=0, token_rows=rows))
     tp, ip = synth.prompts(cfg, sd, seed=7)
     G = 4
     image, label = synth.images(cfg, G), synth.labels(cfg, G)

@@ -315,6 +315,36 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert d["roofline"]["dominant_kernel"]["avg_us"] > 0
 
 
+def test_bench_eight_rank_flow_on_one_gpu():
+    """BASELINE.json configs[2]'s control flow (N = 8, global batch = 8 x per-GPU batch) end to end on this one-GPU box:
+    `python bench.py --gpus 8` re-executes itself under torch.distributed.run; all ranks on cuda:0, gloo instead of
+    RCCL (RCCL refuses several ranks on one device).  Exercises: ONE weight generation per node (local rank 0 writes,
+    seven ranks memory-map), eight shards of distinct synthetic data, prompt broadcast, per-step all-reduce of the
+    flat gradient buffer over 8 ranks, barriers, max-over-ranks timing, exactly one JSON line with the GLOBAL batch and
+    the measured collective time.  No scaling curve: 8 ranks share one GPU here."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RPO_DIST_BACKEND="gloo", RPO_ALL_RANKS_ON_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp8"
+    assert d["scaling"] == "weak" and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+    assert "8 ranks" in d["config"]["collective"]
+    assert d["config"]["collective_us"] > 0 and d["config"]["collective_bytes"] == 4 * 24 * (512 + 768)
+    assert "cpu_baseline" not in d and "precision" not in d      # N = 1 only
+    assert not glob.glob(os.path.join(tempfile.gettempdir(), f"rpo_amd_weights_{os.getuid()}_*")), "shared weight file left behind"
+
+
 @pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1), (4, 300, 2)])
 def test_edge_shapes_against_oracle_f32(K, n_cls, B):
     """K = 1 (reference asserts K >= 1), a class count that is not 19, the largest K that still fits the
@@ -467,12 +497,13 @@ def test_full_size_matches_reference_golden(fixture, model, K, B, act):
         assert (logits.argmax(-1) == g["logits"].argmax(-1)).all()
 
 
-@pytest.mark.parametrize("act,tol", [(torch.float32, TOL_F32), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)],
+@pytest.mark.parametrize("act,tol", [(torch.float32, 1e-6), (torch.float16, 1e-4), (torch.bfloat16, TOL_F32)],
                          ids=["float32", "float16", "bfloat16"])
 def test_full_size_sgd_steps_match_reference(act, tol):
     """configs[1] through the trainer (graphs, fused SGD): the prompts after 1 and 2 optimiser steps at B = 32 against
     the reference's torch.optim.SGD run with the same explicit hyper-parameters.  The prompts move by lr x gradient
-    ~ 1e-2 x 1e-1 per step, so the 16-bit modes' gradient error (0.3 % / 2.5 %) is far inside the bounds."""
+    ~ 1e-2 x 1e-1 per step, so even the bf16 mode's 2.5 % gradient error leaves the LEARNED PROMPTS within the north
+    star's 1e-3 of the reference (measured: f32 1.5e-8, f16 5.8e-6, bf16 6.3e-5 after two steps)."""
     from rpo_amd.trainer import RPO, OptimConfig
     g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_full_k24_b32.npz")))
     cfg, sd, toks, tp, ip, _, _ = _full_workload("ViT-B/16", 24, 32)
@@ -625,6 +656,8 @@ def test_anomaly_scan_and_bad_labels():
     # guarded optimiser step then skips it and leaves the prompts untouched
     assert torch.isnan(tr.engine.grads).any()
     from rpo_amd import ops
+    tr.engine.params.fill_(0.25)                 # (the NaN image above left NaN prompts behind)
+    tr.engine.mom.zero_()
     before = tr.engine.params.clone()
     found = torch.zeros(2, dtype=torch.int32, device="cuda")
     ops.sgd_step_guarded(tr.engine.params, tr.engine.grads, tr.engine.mom, 0.01, 0.9, 5e-4, 1.0, first_step=False,
@@ -747,3 +780,60 @@ def test_coop_context_inference_matches_reference_trainer(tag, depth, B, mode):
     err = np.abs(logits - gold["logits"]).max()
     assert err <= tol, f"{mode}: logits differ from the reference by {err:.3e} (bound {tol})"
     assert np.abs(before - gold["logits"]).max() > min(10 * tol, 0.5)
+
+
+@pytest.mark.parametrize("tag,depth,B,n_ctx", [("d2_b3_ctx4", 2, 3, 4), ("d2_b2_ctx16", 2, 2, 16)])
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_coop_context_training_matches_reference_trainer(tag, depth, B, n_ctx, mode):
+    """Row f4, CoOp TRAINING (trainers/coop.py:258-281): logits, cross-entropy and d loss / d ctx of the HIP path -- the
+    dense text-tower backward, causal attention with dK / dV -- against the reference's own coop.CustomCLIP +
+    F.cross_entropy + backward (tests/golden/ref_coop_*.npz, written by tools/make_golden_plainclip.py)."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoOpCustomCLIP
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_coop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[mode]
+    m = CoOpCustomCLIP(sd, gold["tokenized_prompts"], n_ctx, "cuda:0", dt, max_batch=4, ctx=gold["ctx"])
+    image = torch.from_numpy(synth.images(cfg, B)).cuda()
+    label = torch.from_numpy(gold["label"]).cuda()
+    eng = m.engine
+    logits = eng.coop_forward_backward(image, label).cpu().numpy()
+    loss, g = eng.loss.item(), eng.coop_grad.cpu().numpy()
+    le, ll, gr = np.abs(logits - gold["logits"]).max(), abs(loss - float(gold["loss"])), _relmax(g, gold["ctx_grad"])
+    print(f"[coop {tag} {mode}] logits err {le:.3e} loss err {ll:.3e} ctx_grad rel {gr:.3e}")
+    lt, gt = {"f32": (TOL_F32, TOL_F32), "f16": (F16_LOGIT_ATOL, F16_GRAD_REL), "bf16": (BF16_LOGIT_ATOL, BF16_GRAD_REL)}[mode]
+    assert le <= lt and ll <= lt and gr <= gt
+    assert np.array_equal(m(image).cpu().numpy(), logits)                       # eval branch: same logits, no backward
+    # determinism: the same batch again -> the same bits
+    eng.coop_forward_backward(image, label)
+    assert np.array_equal(eng.coop_grad.cpu().numpy(), g)
+
+
+def test_coop_trainer_sgd_steps_match_oracle():
+    """Three optimiser steps of the CoOp trainer (f32 mode) against the CPU oracle's autograd + torch-equivalent SGD on
+    the same batches: ctx within 1e-3 (measured ~1e-7), losses within 1e-3; the oracle itself is pinned to the
+    reference's coop trainer by tests/test_oracle_golden.py."""
+    from oracle.rpo_oracle import OracleSGD, coop_loss_and_grad
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoOp
+    from rpo_amd.trainer import OptimConfig
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_coop_d2_b3_ctx4.npz")))
+    cfg = vit_b16(layers_v=2, layers_t=2, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    toks, ctx0 = gold["tokenized_prompts"], gold["ctx"]
+    oc = OptimConfig(lr=0.002, momentum=0.9, weight_decay=5e-4, warmup_epoch=0, lr_scheduler="constant")
+    tr = CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3, num_batches=10 ** 9, ctx=ctx0)
+    ctx = torch.from_numpy(ctx0.copy())
+    opt = OracleSGD(oc.lr, oc.momentum, oc.weight_decay)
+    for step in range(3):
+        im, lb = synth.images(cfg, 3, seed=70 + step), synth.labels(cfg, 3, seed=80 + step)
+        _, loss, g = coop_loss_and_grad(sd, im, toks, ctx.numpy(), lb, cfg.patch)
+        opt.step([ctx], [g])
+        out = tr.forward_backward({"img": torch.from_numpy(im), "label": torch.from_numpy(lb)})
+        assert abs(out["loss"] - float(loss)) <= TOL_F32 and 0.0 <= out["acc"] <= 100.0
+        err = (tr.model.prompt_learner.ctx.cpu() - ctx).abs().max().item()
+        print(f"[coop sgd] step {step + 1}: loss {out['loss']:.5f} ctx err {err:.2e}")
+        assert err <= 1e-5
+    sdict = tr.model.prompt_learner.state_dict()                              # the reference's checkpoint keys
+    assert set(sdict) == {"ctx", "token_prefix", "token_suffix"} and sdict["token_suffix"].shape == (19, 77 - 1 - 4, 512)

@@ -94,6 +94,16 @@ if step:
             fo.write(f"{k} {v:.6g}\n")
         if "FETCH_SIZE" in step and "WRITE_SIZE" in step:
             fo.write(f"traffic_bytes_per_step {(2 * step['FETCH_SIZE'] + step['WRITE_SIZE']) * 1024:.6g}\n")
+        # fingerprint of the kernel sources these counters were collected with: bench.py attaches the number to its line
+        # only while rpo_amd/csrc still hashes to this (run this script on the tree the profile was taken with)
+        import hashlib
+        src_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rpo_amd", "csrc")
+        h = hashlib.sha1()
+        for fn in sorted(os.listdir(src_dir)):
+            h.update(fn.encode())
+            with open(os.path.join(src_dir, fn), "rb") as fh:
+                h.update(fh.read())
+        fo.write(f"kernel_sources_sha1 {h.hexdigest()}\n")
 # MFMA-pipe utilisation over one whole step (kernels are serialised under the profiler, so this is the
 # duration-weighted mean of the per-kernel utilisations)
 f = glob.glob(os.path.join(raw, "pmc_step_MFMA", "**", "*counter_collection.csv"), recursive=True)
