@@ -239,6 +239,15 @@ int rpo_text_attn_bwd_dense(const void* q, const void* k, const void* v, int64_t
                             void* dq, void* dk, void* dv, int64_t ldd, int dtype, const int32_t* len, int n_cls,
                             int Lmax, int H, float scale, void* stream);
 
+/* CoCoOp's meta-net (trainers/cocoop.py:93-97, PromptLearner.forward :137-143): bias[b] = linear2(relu(linear1(f[b] /
+ * |f[b]|))) for the B raw image features img_f [B, e]; w1 [h, e], b1 [h], w2 [d, h], b2 [d], all fp32.  f_norm [B, e] and
+ * hidden [B, h] are kept for rpo_metanet_bwd, which turns d_bias [B, d] into the gradients of the four tensors (batch sum
+ * in fixed order).  (e + h) * 4 and B * h * 4 bytes must fit 48 KB of LDS. */
+int rpo_metanet_fwd(const float* img_f, const float* w1, const float* b1, const float* w2, const float* b2,
+                    float* f_norm, float* hidden, float* bias, int B, int e, int h, int d, void* stream);
+int rpo_metanet_bwd(const float* d_bias, const float* f_norm, const float* hidden, const float* w2,
+                    float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int e, int h, int d, void* stream);
+
 /* Cosine-logit head, cross-entropy and their backward (trainers/rpo.py:215-230):
  *   logits[b,c] = (scale_exp / K) * sum_i <img_f[b,i]/|.|, text_f[c,i]/|.|>
  *   loss = mean_b CE(logits[b], label[b])

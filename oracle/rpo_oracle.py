@@ -281,6 +281,49 @@ def coop_loss_and_grad(state_dict, image, tokens, ctx, label, patch: int):
     return logits.detach(), loss.detach(), c.grad.clone()
 
 
+def cocoop_loss_and_grads(state_dict, image, tokens, ctx, meta, label, patch: int):
+    """trainers/cocoop.py:166-192 (CustomCLIP.forward) + :262-265 (fp32 branch): instance-conditioned context.
+    image features (plain image tower, L2-normalised, :173-174) -> meta_net = linear1 [e/16, e] -> ReLU -> linear2
+    [d_t, e/16] (:93-97) -> bias[b]; prompts of image b = [SOS | ctx + bias[b] | name . EOT] for every class (:137-153);
+    logits[b] = exp(logit_scale) * imf_n[b] @ normalise(text_features(prompts_b))^T (:183-187); loss = mean CE.
+    meta: dict with w1 [h, e], b1 [h], w2 [d_t, h], b2 [d_t].  Returns (logits [B, n_cls], loss, {"ctx", "w1", "b1", "w2",
+    "b2"} gradients)."""
+    sd = {k: _t(v).float() for k, v in state_dict.items()}
+    image, tokens = _t(image).float(), _t(tokens).long()
+    d_t, d_v = sd["ln_final.weight"].shape[0], sd["visual.class_embedding"].shape[0]
+    B = image.shape[0]
+    with torch.no_grad():                                            # frozen image tower (:220-222 freeze everything else)
+        emb = F.conv2d(image, sd["visual.conv1.weight"], stride=patch)
+        emb = emb.reshape(B, emb.shape[1], -1).permute(0, 2, 1)
+        x = torch.cat([sd["visual.class_embedding"].repeat(B, 1, 1), emb], dim=1) + sd["visual.positional_embedding"]
+        x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"]).permute(1, 0, 2)
+        S = x.shape[0]
+        for blk in _blocks(sd, "visual.transformer.resblocks."):
+            x = res_block(x, blk, d_v // HEAD_DIM, torch.zeros(S, S))
+        img_f = layer_norm(x.permute(1, 0, 2)[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
+        imf = img_f / img_f.norm(dim=-1, keepdim=True)
+    P = {k: _t(v).float().clone().requires_grad_(True) for k, v in dict(meta, ctx=ctx).items()}
+    bias = F.linear(F.relu(F.linear(imf, P["w1"], P["b1"])), P["w2"], P["b2"])            # [B, d_t]
+    emb_t = sd["token_embedding.weight"][tokens]                                          # [n_cls, T, d_t]
+    n_cls, T, n_ctx = emb_t.shape[0], emb_t.shape[1], P["ctx"].shape[0]
+    causal = torch.full((T, T), float("-inf")).triu_(1)
+    logits = []
+    for b in range(B):
+        c = (P["ctx"] + bias[b][None]).unsqueeze(0).expand(n_cls, -1, -1)
+        t = torch.cat([emb_t[:, :1], c, emb_t[:, 1 + n_ctx:]], dim=1)
+        t = (t + sd["positional_embedding"]).permute(1, 0, 2)
+        for blk in _blocks(sd, "transformer.resblocks."):
+            t = res_block(t, blk, d_t // HEAD_DIM, causal)
+        t = layer_norm(t.permute(1, 0, 2), sd["ln_final.weight"], sd["ln_final.bias"])
+        tf = t[torch.arange(n_cls), tokens.argmax(dim=-1)] @ sd["text_projection"]
+        tf = tf / tf.norm(dim=-1, keepdim=True)
+        logits.append(sd["logit_scale"].exp() * imf[b] @ tf.t())
+    logits = torch.stack(logits)
+    loss = F.cross_entropy(logits, _t(label).long())
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: v.grad.clone() for k, v in P.items()}
+
+
 # ---------------------------------------------------------------------------
 # optimiser (torch.optim.SGD restated; Dassl's defaults are not in the tree, so
 # momentum / weight decay / dampening are explicit -- SURVEY.md section 8c)

@@ -82,6 +82,8 @@ SIGNATURES = {
                                   c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_text_attn_bwd_dense": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
                                         c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_metanet_fwd": (c_i32, [c_vp] * 8 + [c_i32] * 4 + [c_vp]),
+    "rpo_metanet_bwd": (c_i32, [c_vp] * 8 + [c_i32] * 4 + [c_vp]),
     "rpo_head_workspace_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "rpo_head_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                  c_vp, c_vp]),

@@ -1,4 +1,4 @@
-"""CoOp on the HIP engine: the host-side mirror of `trainers/coop.py` (PromptLearner :60-134, CustomCLIP :185-208, the
+"""CoOp and CoCoOp on the HIP engine: the host-side mirror of `trainers/coop.py` (PromptLearner :60-134, CustomCLIP :185-208, the
 `CoOp` trainer's `forward_backward` :258-281) -- SURVEY.md section 8f rank 4, the sibling trainer that shares RPO's towers
 without the read-only mask.
 
@@ -11,6 +11,11 @@ Unlike RPO's prompts, a context vector is read by every later token, so its grad
 frozen CLIP and is only run forward.  Generic context (CSC = False) and class token at the end -- the reference's own
 defaults (configs/trainers/CoOp/vit_b16_ep50.yaml) -- are what is built; "middle" / "front" raise in the reference
 config used here as well (its code path for them exists but is not exercised by the repo's scripts).
+
+CoCoOp (`trainers/cocoop.py`: PromptLearner :60-153, CustomCLIP :156-192, trainer :255-275) adds a meta-net on the
+normalised image feature whose output shifts the context PER IMAGE, so every image has its own text features for every
+class: `Engine.cocoop_forward_backward` runs the class set once per image (B * n_cls virtual classes) through the same
+dense text path and trains ctx + the two meta-net layers (`CoCoOpCustomCLIP`, `CoCoOp` below).
 
 The caller provides the token ids of the "X X .. name." prompts (the BPE tokenizer is out of scope).
 """
@@ -114,8 +119,8 @@ class CoOp:
         with torch.cuda.device(self.device):
             image, label = self.parse_batch_train(batch)
             logits = eng.coop_forward_backward(image, label)
-            ops.sgd_step(eng.coop_ctx.view(-1), eng.coop_grad.view(-1), eng.coop_mom.view(-1), self.lr, oc.momentum,
-                         oc.weight_decay, 1.0, first_step=(self._steps == 0))
+            ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
+                         first_step=(self._steps == 0))
             self._steps += 1
             acc = float((logits.argmax(1) == label).float().mean().item()) * 100.0      # compute_accuracy()[0]
             summary = {"loss": float(eng.loss.item()), "acc": acc}
@@ -130,3 +135,87 @@ class CoOp:
     @torch.no_grad()
     def model_inference(self, image: torch.Tensor) -> torch.Tensor:
         return self.model(image)
+
+
+class CoCoOpPromptLearner(CoOpPromptLearner):
+    """`trainers/cocoop.py:PromptLearner`: ctx + meta_net (linear1 [e/16, e] -> ReLU -> linear2 [d_t, e/16], :93-97)."""
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        w1, b1, w2, b2 = (t.detach().cpu().clone() for t in self.engine.meta)
+        return {"ctx": self.ctx.detach().cpu().clone(), "meta_net.linear1.weight": w1, "meta_net.linear1.bias": b1,
+                "meta_net.linear2.weight": w2, "meta_net.linear2.bias": b2,
+                "token_prefix": self.token_prefix.clone(), "token_suffix": self.token_suffix.clone()}
+
+
+class CoCoOpCustomCLIP:
+    """`trainers/cocoop.py:CustomCLIP`: `model(image)` -> logits [B, n_cls]; `model(image, label)` -> the cross-entropy
+    (a device scalar) when the prompt learner is in training mode (:188-189)."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int,
+                 device: str | torch.device = "cuda:0", act_dtype: torch.dtype = torch.float16, max_batch: int = 1,
+                 ctx: Optional[np.ndarray] = None, meta: Optional[Dict[str, np.ndarray]] = None,
+                 cfg: Optional[RPOConfig] = None):
+        tokens = np.asarray(tokenized_prompts, dtype=np.int64)
+        if cfg is None:
+            cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])
+        self.cfg = cfg
+        self.engine = eng = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        e, dt = cfg.embed, cfg.d_t
+        h = e // 16                                                          # vis_dim // 16 (:94)
+        with torch.cuda.device(eng.dev):
+            eng.coop_setup(n_ctx, replicas=max_batch, meta_hidden=h)
+            if ctx is None:                                                  # the reference's draws, in its order:
+                ctx = torch.empty(n_ctx, dt).normal_(std=0.02).numpy()       # nn.init.normal_(ctx_vectors, std=0.02) (:83-84)
+            if meta is None:                                                 # then nn.Linear's default initialisation
+                l1, l2 = torch.nn.Linear(e, h), torch.nn.Linear(h, dt)
+                meta = dict(w1=l1.weight.detach().numpy(), b1=l1.bias.detach().numpy(),
+                            w2=l2.weight.detach().numpy(), b2=l2.bias.detach().numpy())
+            eng.coop_ctx.copy_(torch.as_tensor(np.asarray(ctx, dtype=np.float32)))
+            for t, k in zip(eng.meta, ("w1", "b1", "w2", "b2")):
+                t.copy_(torch.as_tensor(np.asarray(meta[k], dtype=np.float32)))
+        self.prompt_learner = CoCoOpPromptLearner(eng, n_ctx, state_dict["token_embedding.weight"], tokens)
+        self.tokenized_prompts = tokens
+
+    def __call__(self, image: torch.Tensor, label: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eng = self.engine
+        with torch.cuda.device(eng.dev):
+            image = image.to(device=eng.dev, dtype=torch.float32).contiguous()
+            if self.prompt_learner.training and label is not None:
+                eng.cocoop_forward_backward(image, label.to(eng.dev, dtype=torch.int64))
+                return eng.loss[0]
+            return eng.cocoop_forward_backward(image, None)
+
+
+class CoCoOp(CoOp):
+    """The trainer's step (trainers/cocoop.py:255-275): loss = model(image, label) -> zero_grad -> backward -> SGD step
+    on ctx and the meta-net; returns {"loss"} (no accuracy: the model returns the loss itself in training mode)."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int = 4,
+                 optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
+                 act_dtype: torch.dtype = torch.float16, batch_size: int = 1, num_batches: int = 1,
+                 ctx: Optional[np.ndarray] = None, meta: Optional[Dict[str, np.ndarray]] = None,
+                 cfg: Optional[RPOConfig] = None):
+        self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=10)    # configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1.yaml
+        self.model = CoCoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, meta, cfg)
+        self.engine, self.cfg = self.model.engine, self.model.cfg
+        self.device = self.engine.dev
+        self.batch_size, self.num_batches = batch_size, num_batches
+        self.epoch = self.batch_idx = self._steps = 0
+        self.lr = lr_at_epoch(self.optim_cfg, 0)
+
+    def forward_backward(self, batch) -> Dict[str, float]:
+        eng, oc = self.engine, self.optim_cfg
+        with torch.cuda.device(self.device):
+            image, label = self.parse_batch_train(batch)
+            eng.cocoop_forward_backward(image, label)
+            ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
+                         first_step=(self._steps == 0))
+            self._steps += 1
+            summary = {"loss": float(eng.loss.item())}
+        if (self.batch_idx + 1) == self.num_batches:
+            self.epoch += 1
+            self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+            self.batch_idx = 0
+        else:
+            self.batch_idx += 1
+        return summary

@@ -548,6 +548,112 @@ extern "C" int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, con
   return rpo_launch_status();
 }
 
+// ---- CoCoOp's meta-net (trainers/cocoop.py:93-97, :137-143) -----------------------------------------------------------
+// bias[b] = linear2(relu(linear1(f[b] / |f[b]|))): vis_dim -> vis_dim / 16 -> ctx_dim, one workgroup per image; the
+// normalised feature and the hidden activation are kept for the backward.  fp32 throughout (the reference's fp16 branch
+// halves the meta-net; fp32 is its PREC = fp32 / amp behaviour).
+__global__ __launch_bounds__(256) void metanet_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* fn, float* hid,
+                                                          float* bias, int e, int h, int d) {
+  extern __shared__ float mn_smem[];               // fn [e] | hid [h]
+  __shared__ float red[4];
+  float* sf = mn_smem;
+  float* sh = mn_smem + e;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ss = 0.f;
+  for (int i = tid; i < e; i += 256) { const float v = f[(int64_t)b * e + i]; ss = fmaf(v, v, ss); }
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / sqrtf(ss);
+  for (int i = tid; i < e; i += 256) {
+    const float v = f[(int64_t)b * e + i] * inv;
+    sf[i] = v;
+    fn[(int64_t)b * e + i] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < h; j += 4) {              // one wave per hidden unit: fixed-order lane partials + wave_sum
+    float a = 0.f;
+    for (int i = lane; i < e; i += 64) a = fmaf(w1[(int64_t)j * e + i], sf[i], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+      const float v = fmaxf(a + b1[j], 0.f);
+      sh[j] = v;
+      hid[(int64_t)b * h + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < d; o += 256) {
+    float a = b2[o];
+    for (int j = 0; j < h; ++j) a = fmaf(w2[(int64_t)o * h + j], sh[j], a);
+    bias[(int64_t)b * d + o] = a;
+  }
+}
+
+// Gradients of the four meta-net tensors given dbias [B, d] (sum over the batch in fixed order b = 0 .. B-1):
+//   g_w2[o][j] = sum_b dbias[b][o] hid[b][j];  g_b2[o] = sum_b dbias[b][o];
+//   dhid[b][j] = (hid[b][j] > 0) sum_o dbias[b][o] w2[o][j];  g_w1[j][i] = sum_b dhid[b][j] fn[b][i];  g_b1[j] = sum_b dhid[b][j]
+// Every block recomputes dhid (B * h dot products of length d: a few thousand MACs) into LDS, then owns 256 outputs.
+__global__ __launch_bounds__(256) void metanet_bwd_kernel(const float* __restrict__ dbias, const float* __restrict__ fn,
+                                                          const float* __restrict__ hid, const float* __restrict__ w2,
+                                                          float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int e,
+                                                          int h, int d) {
+  extern __shared__ float mn_smem[];               // dhid [B][h]
+  const int tid = threadIdx.x;
+  for (int p = tid; p < B * h; p += 256) {
+    const int b = p / h, j = p - b * h;
+    float a = 0.f;
+    for (int o = 0; o < d; ++o) a = fmaf(dbias[(int64_t)b * d + o], w2[(int64_t)o * h + j], a);
+    mn_smem[p] = hid[(int64_t)b * h + j] > 0.f ? a : 0.f;
+  }
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t n_w2 = (int64_t)d * h, n_w1 = (int64_t)h * e;
+  if (idx < n_w2) {
+    const int o = (int)(idx / h), j = (int)(idx - (int64_t)o * h);
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(dbias[(int64_t)b * d + o], hid[(int64_t)b * h + j], a);
+    g_w2[idx] = a;
+  } else if (idx < n_w2 + n_w1) {
+    const int64_t k = idx - n_w2;
+    const int j = (int)(k / e), i = (int)(k - (int64_t)j * e);
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(mn_smem[b * h + j], fn[(int64_t)b * e + i], a);
+    g_w1[k] = a;
+  } else if (idx < n_w2 + n_w1 + d) {
+    const int o = (int)(idx - n_w2 - n_w1);
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dbias[(int64_t)b * d + o];
+    g_b2[o] = a;
+  } else if (idx < n_w2 + n_w1 + d + h) {
+    const int j = (int)(idx - n_w2 - n_w1 - d);
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += mn_smem[b * h + j];
+    g_b1[j] = a;
+  }
+}
+
+extern "C" int rpo_metanet_fwd(const float* img_f, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* f_norm, float* hidden, float* bias, int B, int e, int h, int d, void* stream) {
+  if (!img_f || !w1 || !b1 || !w2 || !b2 || !f_norm || !hidden || !bias || B <= 0 || e <= 0 || h <= 0 || d <= 0)
+    return RPO_E_BADARG;
+  if ((e + h) * 4 > 48 * 1024) return RPO_E_SHAPE;
+  hipLaunchKernelGGL(metanet_fwd_kernel, dim3(B), dim3(256), (e + h) * 4, static_cast<hipStream_t>(stream), img_f, w1,
+                     b1, w2, b2, f_norm, hidden, bias, e, h, d);
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_metanet_bwd(const float* d_bias, const float* f_norm, const float* hidden, const float* w2,
+                               float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int e, int h, int d,
+                               void* stream) {
+  if (!d_bias || !f_norm || !hidden || !w2 || !g_w1 || !g_b1 || !g_w2 || !g_b2 || B <= 0 || e <= 0 || h <= 0 || d <= 0)
+    return RPO_E_BADARG;
+  if ((int64_t)B * h * 4 > 48 * 1024) return RPO_E_SHAPE;
+  const int64_t n = (int64_t)d * h + (int64_t)h * e + d + h;
+  hipLaunchKernelGGL(metanet_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), B * h * 4,
+                     static_cast<hipStream_t>(stream), d_bias, f_norm, hidden, w2, g_w1, g_b1, g_w2, g_b2, B, e, h, d);
+  return rpo_launch_status();
+}
+
 extern "C" int rpo_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd,
                             float grad_scale, int first_step, void* stream) {
   if (!p || !g || !buf || n <= 0) return RPO_E_BADARG;

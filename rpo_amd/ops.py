@@ -245,6 +245,25 @@ def head_fwd_bwd(img_f, text_f, label, scale_exp: float, logits, loss, d_img_f, 
     return logits
 
 
+def metanet_fwd(img_f, w1, b1, w2, b2, f_norm, hidden, bias):
+    B, e = img_f.shape
+    h, d = w1.shape[0], w2.shape[0]
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (img_f, w1, b1, w2, b2, f_norm, hidden, bias))
+    check(_lib.load().rpo_metanet_fwd(img_f.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                      f_norm.data_ptr(), hidden.data_ptr(), bias.data_ptr(), B, e, h, d, _stream()),
+          "rpo_metanet_fwd")
+    return bias
+
+
+def metanet_bwd(d_bias, f_norm, hidden, w2, g_w1, g_b1, g_w2, g_b2):
+    B, d = d_bias.shape
+    e, h = f_norm.shape[1], hidden.shape[1]
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (d_bias, f_norm, hidden, w2, g_w1, g_b1, g_w2, g_b2))
+    check(_lib.load().rpo_metanet_bwd(d_bias.data_ptr(), f_norm.data_ptr(), hidden.data_ptr(), w2.data_ptr(),
+                                      g_w1.data_ptr(), g_b1.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr(), B, e, h, d,
+                                      _stream()), "rpo_metanet_bwd")
+
+
 def sgd_step(p, g, buf, lr: float, momentum: float, wd: float, grad_scale: float, first_step: bool):
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
     check(_lib.load().rpo_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr, momentum, wd,

@@ -837,3 +837,66 @@ def test_coop_trainer_sgd_steps_match_oracle():
         assert err <= 1e-5
     sdict = tr.model.prompt_learner.state_dict()                              # the reference's checkpoint keys
     assert set(sdict) == {"ctx", "token_prefix", "token_suffix"} and sdict["token_suffix"].shape == (19, 77 - 1 - 4, 512)
+
+
+@pytest.mark.parametrize("tag,depth,B,n_ctx", [("d2_b1_ctx4", 2, 1, 4), ("d2_b3_ctx4", 2, 3, 4)])
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_cocoop_training_matches_reference_trainer(tag, depth, B, n_ctx, mode):
+    """Row f4, CoCoOp (trainers/cocoop.py:137-153,166-192,255-275): meta-net conditioned context, per-image text
+    features.  Logits, cross-entropy and the gradient of every trained tensor (ctx, meta_net.linear1 / linear2 weight and
+    bias) of the HIP path against the reference's own cocoop.CustomCLIP + backward (tests/golden/ref_cocoop_*.npz)."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoCoOpCustomCLIP
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_cocoop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[mode]
+    meta = {k: gold[k] for k in ("w1", "b1", "w2", "b2")}
+    m = CoCoOpCustomCLIP(sd, gold["tokenized_prompts"], n_ctx, "cuda:0", dt, max_batch=B, ctx=gold["ctx"], meta=meta)
+    image = torch.from_numpy(synth.images(cfg, B)).cuda()
+    label = torch.from_numpy(gold["label"]).cuda()
+    eng = m.engine
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    m.prompt_learner.train()
+    loss = m(image, label).item()
+    le, ll = np.abs(logits - gold["logits"]).max(), abs(loss - float(gold["loss"]))
+    got = dict(ctx=eng.coop_grad, w1=eng.meta_grad[0], b1=eng.meta_grad[1], w2=eng.meta_grad[2], b2=eng.meta_grad[3])
+    rel = {k: _relmax(v.cpu().numpy(), gold["g_" + k]) for k, v in got.items()}
+    print(f"[cocoop {tag} {mode}] logits err {le:.3e} loss err {ll:.3e} grads rel " +
+          " ".join(f"{k} {v:.2e}" for k, v in rel.items()))
+    lt, gt = {"f32": (TOL_F32, TOL_F32), "f16": (F16_LOGIT_ATOL, F16_GRAD_REL), "bf16": (BF16_LOGIT_ATOL, BF16_GRAD_REL)}[mode]
+    assert le <= lt and ll <= lt
+    assert all(v <= gt for v in rel.values()), rel
+
+
+def test_cocoop_trainer_sgd_steps_match_oracle():
+    """Two optimiser steps of the CoCoOp trainer (f32 mode, batch 2) against the CPU oracle's autograd + SGD on the same
+    batches: every trained tensor within 1e-5."""
+    from oracle.rpo_oracle import OracleSGD, cocoop_loss_and_grads
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoCoOp
+    from rpo_amd.trainer import OptimConfig
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_cocoop_d2_b3_ctx4.npz")))
+    cfg = vit_b16(layers_v=2, layers_t=2, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    toks = gold["tokenized_prompts"]
+    keys = ("ctx", "w1", "b1", "w2", "b2")
+    P = {k: torch.from_numpy(gold[k].copy()) for k in keys}
+    oc = OptimConfig(lr=0.002, momentum=0.9, weight_decay=5e-4, warmup_epoch=0, lr_scheduler="constant")
+    tr = CoCoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=2, num_batches=10 ** 9, ctx=gold["ctx"],
+                meta={k: gold[k] for k in keys[1:]})
+    opt = OracleSGD(oc.lr, oc.momentum, oc.weight_decay)
+    for step in range(2):
+        im, lb = synth.images(cfg, 2, seed=70 + step), synth.labels(cfg, 2, seed=80 + step)
+        _, loss, g = cocoop_loss_and_grads(sd, im, toks, P["ctx"].numpy(), {k: P[k].numpy() for k in keys[1:]}, lb, cfg.patch)
+        opt.step([P[k] for k in keys], [g[k] for k in keys])
+        out = tr.forward_backward({"img": torch.from_numpy(im), "label": torch.from_numpy(lb)})
+        assert abs(out["loss"] - float(loss)) <= TOL_F32
+        have = dict(zip(keys, [tr.engine.coop_ctx] + list(tr.engine.meta)))
+        err = max((have[k].cpu() - P[k]).abs().max().item() for k in keys)
+        print(f"[cocoop sgd] step {step + 1}: loss {out['loss']:.5f} max parameter err {err:.2e}")
+        assert err <= 1e-5
+    assert set(tr.model.prompt_learner.state_dict()) == {"ctx", "meta_net.linear1.weight", "meta_net.linear1.bias",
+                                                         "meta_net.linear2.weight", "meta_net.linear2.bias",
+                                                         "token_prefix", "token_suffix"}

@@ -151,3 +151,23 @@ def test_coop_oracle_matches_reference_trainer(tag, depth, B, n_ctx):
     assert np.abs(logits.numpy() - gold["logits"]).max() <= 3e-5
     assert abs(float(loss) - float(gold["loss"])) <= 1e-5
     assert np.abs(g.numpy() - gold["ctx_grad"]).max() <= 2e-5 * np.abs(gold["ctx_grad"]).max()
+
+
+@pytest.mark.parametrize("tag,depth,B", [("d2_b1_ctx4", 2, 1), ("d2_b3_ctx4", 2, 3)])
+def test_cocoop_oracle_matches_reference_trainer(tag, depth, B):
+    """oracle.rpo_oracle.cocoop_loss_and_grads against the reference's own cocoop.CustomCLIP + backward
+    (tests/golden/ref_cocoop_*.npz, tools/make_golden_cocoop.py): logits, loss, and the gradient of every trained tensor
+    (ctx, meta-net weights and biases)."""
+    import os
+    from helpers import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, f"ref_cocoop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    image = synth.images(cfg, B)
+    meta = {k: g[k] for k in ("w1", "b1", "w2", "b2")}
+    logits, loss, grads = rpo_oracle.cocoop_loss_and_grads(sd, image, g["tokenized_prompts"], g["ctx"], meta, g["label"], cfg.patch)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=3e-5, rtol=0)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    for k in ("ctx", "w1", "b1", "w2", "b2"):
+        ref = g["g_" + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k

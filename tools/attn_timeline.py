@@ -15,16 +15,23 @@ lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
-B, H, N, Kp, d = 32, 12, 197, 24, 768
-qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
-out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
-for _ in range(3):
-    buf.zero_()
-    ops.attn_readonly_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], out, B, H, N, Kp)
-torch.cuda.synchronize()
-t = buf.view(8, 64).cpu()
+H, N, Kp, d = 12, 197, 24, 768
 names = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "S^T done", "softmax done", "PV+store issued", "stores drained"]
-for b in range(4):
-    r = t[b]
-    if r[0] == 0: continue
-    print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[i-1])}" for i in range(1, 8)) + f" | total {int(r[7]-r[0])}")
+for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
+    qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
+    out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        buf.zero_()
+        ops.attn_readonly_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], out, B, H, N, Kp)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        ops.attn_readonly_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], out, B, H, N, Kp)
+    e.record(); e.synchronize()
+    print(f"== B={B}: {B * H} workgroups, warm loop {1e3 * s.elapsed_time(e) / 20:.1f} us per launch (debug build, stamps on)")
+    t = buf.view(8, 64).cpu()
+    for b in range(4):
+        r = t[b]
+        if r[0] == 0: continue
+        print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[i-1])}" for i in range(1, 8)) + f" | total {int(r[7]-r[0])}")

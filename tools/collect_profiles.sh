@@ -1,4 +1,5 @@
 #!/bin/bash
+# QUICK=1 skips the probes whose results do not change with the kernels (CU masks, DMA micro-benchmark, ...).
 # Runs on the GPU box: kernel-trace of the default bench + PMC passes over the GEMM micro-benchmark.
 # Output under gpurun_out/profiles_raw/; tools/summarize_profiles.py turns it into profiles/*.txt.
 set -u
@@ -27,11 +28,13 @@ for b in 4 8 16 64 128; do timeout 200 python bench.py --batch $b --steps 40 --w
 timeout 200 python bench.py --dtype f32 --steps 20 --warmup 5 $B > $O/bench_f32.json 2>> $O/bench.err
 timeout 200 python bench.py --dtype f16 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_f16.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench_eval.json 2>> $O/bench.err
-timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
+[ -z "${QUICK:-}" ] && timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
-timeout 300 python tools/probe_cu_mask.py 2>&1 | grep -v amdgpu.ids > $O/cu_mask_probe.txt
+[ -z "${QUICK:-}" ] && timeout 300 python tools/probe_cu_mask.py 2>&1 | grep -v amdgpu.ids > $O/cu_mask_probe.txt
 timeout 100 python tools/probe_per_layer.py > $O/per_layer_probe.txt 2>&1
-BENCH_CFGS=2,3,7,8,10 timeout 200 python tools/bench_gemm.py > $O/bench_gemm.txt 2>&1
-[ -x tools/build/ubench_dma ] && timeout 100 tools/build/ubench_dma > $O/ubench_dma.txt 2>&1
+[ -z "${QUICK:-}" ] && BENCH_CFGS=2,3,7,8,10 timeout 200 python tools/bench_gemm.py > $O/bench_gemm.txt 2>&1
+[ -z "${QUICK:-}" ] && [ -x tools/build/ubench_dma ] && timeout 100 tools/build/ubench_dma > $O/ubench_dma.txt 2>&1
+# the image tower as P part-batches on P streams (round 3: does de-phasing the one-round kernels help?)
+timeout 200 python tools/probe_half_batch.py 32 1 2 4 2>&1 | grep -v amdgpu.ids > $O/half_batch_probe.txt
 ls $O
