@@ -398,6 +398,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
+      // (issuing the score tile of key tile t+1 before the softmax arithmetic of tile t -- one more live tile, 118 VGPRs --
+      //  measured nothing: loop 9.5 k vs 9.7 k cycles per workgroup, in-step 14.7 vs 13.6 us, step 3.008 vs 3.009 ms)
       f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
       const float mn = fmaxf(m, mask_and_max(sc, t, N, half));     // finite from tile 0 on (N >= 1)
       const float alpha = exp_scalar<T>(m - mn, scale);           // first tile: exp(-inf) = 0
