@@ -125,6 +125,13 @@ typedef struct rpo_gemm_args {
      quickgelu'(u).  in_dtype (16-bit modes only): d quickgelu / du itself in the act dtype ([rows, ldaux] of that type) --
      *_QGELU epilogues write it, QGELU_BWD multiplies by it: half the bytes, no transcendental in the backward. */
   int32_t aux_dtype;
+  /* Optional hint (results do not depend on it; may be NULL): `prefetch_bytes` bytes at `prefetch` are what the NEXT
+     launch on this stream will read first -- in the image tower the next GEMM's frozen weight matrix, which no cache
+     still holds a whole step after its last use.  The one-round kernels have every workgroup touch its 1 / grid share
+     of those lines (one dword per 128-B line, issued before the k-loop) so that the next kernel finds them in the
+     memory-side cache instead of HBM.  Kernels that do not implement the hint ignore it. */
+  const void* prefetch;
+  int64_t prefetch_bytes;
 } rpo_gemm_args;
 
 int rpo_version(void);

@@ -50,6 +50,7 @@ class GemmArgs(C.Structure):
         ("seg_rows0", c_i32), ("seg_rows1", c_i32), ("seg1_row0", c_i32),
         ("ln_group", c_i32),
         ("aux_dtype", c_i32),
+        ("prefetch", c_vp), ("prefetch_bytes", c_i64),
     ]
 
 

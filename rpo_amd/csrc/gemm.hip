@@ -58,7 +58,31 @@ struct GemmParams {
   float ln_eps;
   int seg_rows0, seg_rows1, seg1_row0;      // tiling hint: see include/rpo_amd.h
   int ln_group;                             // columns per partial LayerNorm statistic (64, or 96: gemm_w4k.inc)
+  const char* pf_ptr; int64_t pf_bytes;     // prefetch hint (include/rpo_amd.h)
 };
+
+// Prefetch hint: this workgroup's share of the lines at pf_ptr, one dword per 128-B line and lane, REQUESTED before the
+// k-loop and consumed (by an empty asm) after it -- like the LayerNorm statistics the loads are older than every DMA of
+// the loop, so its counted vmcnt waits only get stricter, and nothing waits for them before the loop's own first wait.
+__device__ __forceinline__ uint32_t prefetch_range(const char* ptr, int64_t bytes) {
+  uint32_t v = 0;
+  if (ptr != nullptr) {
+    const int64_t lines = bytes >> 7;
+    const int64_t nblk = (int64_t)gridDim.x * gridDim.y;              // (split-K launches are 2-D)
+    const int64_t per = (lines + nblk - 1) / nblk;
+    const int64_t l0 = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * per;
+    for (int64_t i = threadIdx.x; i < per; i += blockDim.x)
+      if (l0 + i < lines) v ^= *reinterpret_cast<const uint32_t*>(ptr + ((l0 + i) << 7));
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t prefetch_touch(const GemmParams& p) {
+#ifndef RPO_NO_PREFETCH
+  return prefetch_range(p.pf_ptr, p.pf_bytes);
+#else
+  return 0;
+#endif
+}
 
 constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic written by the generic epilogues
 
@@ -552,6 +576,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     epi_preload<EPI, CF, TIn>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
                                               // in-loop DMA, so the counted waits below stay valid (conservative)
   }
+  const uint32_t pf_touch = prefetch_touch(p);     // the same holds for the prefetch hint's loads (GemmParams::pf_ptr)
 
 #ifdef RPO_TIMELINE
   unsigned long long t_wait = 0, t_bar = 0, t_body = 0, t_a, t_b, t_c, t_d;
@@ -620,6 +645,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     g_timeline[(blockIdx.x / 97) * 64 + 55] = t_body;
   }
 #endif
+  asm volatile("" :: "v"(pf_touch));
 
 
   RPO_STAMP(60);
@@ -1029,6 +1055,9 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
   p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
   p.ln_group = a->ln_group == 0 ? LN_GROUP : a->ln_group;
+  p.pf_ptr = static_cast<const char*>(a->prefetch);
+  p.pf_bytes = a->prefetch == nullptr ? 0 : a->prefetch_bytes;
+  if (p.pf_bytes < 0 || (p.pf_ptr != nullptr && reinterpret_cast<uintptr_t>(p.pf_ptr) % 4 != 0)) return RPO_E_BADARG;
   if (p.ln_group != 64 && p.ln_group != 96) return RPO_E_BADARG;
   if (is_ln && (p.K % p.ln_group != 0)) return RPO_E_SHAPE;
   if (p.seg_rows0 < 0 || p.seg_rows1 < 0 || p.seg1_row0 < 0 || p.seg1_row0 > p.M) return RPO_E_BADARG;

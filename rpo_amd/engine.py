@@ -57,6 +57,7 @@ class _Block:
     w_out_t: torch.Tensor                           # [d, d]
     w_fc_t: torch.Tensor                            # [d, 4d]
     w_proj_t: torch.Tensor                          # [4d, d]
+    w_oq_t: Optional[torch.Tensor] = None           # [2, d, d] = (w_out_t, w_q_t) in one allocation (prefetch hint)
     # LayerNorm folded into the consuming GEMM (include/rpo_amd.h RPO_EPI_LN_*; image tower, 16-bit modes):
     # W' = gamma o W (act dtype), s = row sums of the ROUNDED W', b' = b + W beta
     w_in_ln: Optional[torch.Tensor] = None; s_in: Optional[torch.Tensor] = None; b_in_ln: Optional[torch.Tensor] = None
@@ -78,6 +79,9 @@ class Engine:
         # ln_1 / ln_2 of the image blocks ride in the epilogues of the GEMMs around them (16-bit modes; the f32 parity
         # mode keeps the stand-alone LayerNorm kernels, bit for bit what the goldens were validated with)
         self.fold_ln = act_dtype != torch.float32 and os.environ.get("RPO_NO_LN_FOLD") != "1"
+        # prefetch hints on the prompt-row chains (text tower, both backward chains): A/B switch RPO_NO_CHAIN_PREFETCH=1
+        self._pf_chains = (act_dtype != torch.float32 and os.environ.get("RPO_NO_WPREFETCH") != "1"
+                           and os.environ.get("RPO_NO_CHAIN_PREFETCH") != "1")
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -133,8 +137,16 @@ class Engine:
             ln1_w=g("ln_1.weight"), ln1_b=g("ln_1.bias"), ln2_w=g("ln_2.weight"), ln2_b=g("ln_2.bias"),
             w_in=self._act(w_in), b_in=g("attn.in_proj_bias"), w_out=self._act(w_out), b_out=g("attn.out_proj.bias"),
             w_fc=self._act(w_fc), b_fc=g("mlp.c_fc.bias"), w_proj=self._act(w_proj), b_proj=g("mlp.c_proj.bias"),
-            w_q_t=self._act(w_in[:d].t()), w_out_t=self._act(w_out.t()), w_fc_t=self._act(w_fc.t()),
-            w_proj_t=self._act(w_proj.t())))
+            w_fc_t=self._act(w_fc.t()), w_proj_t=self._act(w_proj.t()), **self._oq_t(w_out, w_in[:d])))
+
+    def _oq_t(self, w_out: torch.Tensor, w_q: torch.Tensor) -> dict:
+        """The two d x d dX weights of the attention backward in ONE allocation, so that one prefetch hint
+        (rpo_gemm_args.prefetch) covers both: the d out-proj operand is read first, the d q-proj operand next."""
+        d = w_out.shape[0]
+        both = torch.empty(2, d, d, dtype=self.act, device=self.dev)
+        both[0].copy_(self._act(w_out.t()))
+        both[1].copy_(self._act(w_q.t()))
+        return dict(w_out_t=both[0], w_q_t=both[1], w_oq_t=both)
 
     def _pack(self, sd, tokens) -> None:
         cfg = self.cfg
@@ -271,29 +283,35 @@ class Engine:
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         ops.broadcast_rows(self.text_prompt, self.xt[0], n)          # trainers/rpo.py:176-177
         fold, st, last = self.fold_ln and os.environ.get("RPO_NO_TEXT_FOLD") != "1", self.ln_stats_t, len(self.txt) - 1
+        pf = self._pf_chains
+        nxt_q = lambda l: ((self.txt[l + 1].w_in_ln if fold else self.txt[l + 1].w_in)[:dt] if (pf and l < last) else None)
         for l, blk in enumerate(self.txt):
             kv = self.kv_t[l]
             # LayerNorm folded into the GEMMs around it exactly as in the image tower (_image_forward): the residual
             # GEMMs leave the 16-bit copy of their result in ht and its row statistics in st
             if fold and l > 0:
                 ops.gemm_nt(self.ht, blk.w_in_ln[:dt], self.qt[l], EPI_LN_BIAS, bias=blk.b_in_ln[:dt], ln_stats=st,
-                            ln_colsum=blk.s_in[:dt])
+                            ln_colsum=blk.s_in[:dt], prefetch=blk.w_out if pf else None)
             else:
                 ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
-                ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt])
+                ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt],
+                            prefetch=blk.w_out if pf else None)
             ops.text_attn_fwd(self.qt[l], kv[:, :dt], kv[:, dt:], self.att_t, self.len_i32, n, K, self.Lmax, H,
                               causal=False, scale=SCALE)
             prod = dict(out2=self.ht, ln_stats=st) if fold else {}
-            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod)
+            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod,
+                        prefetch=(blk.w_fc_ln if fold else blk.w_fc) if pf else None)
             if fold:
                 ops.gemm_nt(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
-                            aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc)
+                            aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc,
+                            prefetch=blk.w_proj if pf else None)
             else:
                 ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
                 ops.gemm_nt(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
-                            aux=self.ut[l] if train else None, aux_row0=0)
+                            aux=self.ut[l] if train else None, aux_row0=0, prefetch=blk.w_proj if pf else None)
             prod = dict(out2=self.ht, ln_stats=st) if (fold and l < last) else {}
-            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod)
+            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod,
+                        prefetch=nxt_q(l))
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
         ops.gemm_nt(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 
@@ -305,7 +323,8 @@ class Engine:
         x_pre = self.x_pre[:R]
         ops.im2col_patches(image, self.im2col[:B * cfg.n_patches], cfg.patch)
         ops.gemm_nt(self.im2col[:B * cfg.n_patches], self.conv_w, x_pre, EPI_PATCH, resid=self.pos,
-                    group=cfg.n_patches)                                               # rpo.py:198-202
+                    group=cfg.n_patches,                                               # rpo.py:198-202
+                    prefetch=self.vis[0].w_in if (self._pf_chains and len(self.vis)) else None)
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
         # CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch
         ops.img_embed_norm(x_pre, self.cls, self.pos, self.img_prompt, self.ln_pre[0], self.ln_pre[1], self.x[0][:R],
@@ -325,6 +344,26 @@ class Engine:
         stv = lambda grp: self.ln_stats.view(-1)[:R * (dv // grp) * 2].view(R, dv // grp, 2)
         st_out, st_proj, st64 = stv(g_out), stv(g_proj), self.ln_stats[:R]
         last = len(self.vis) - 1
+        # Prefetch hint (rpo_gemm_args.prefetch): every big GEMM names the frozen weight matrix the NEXT GEMM of the chain
+        # reads -- a whole step after its last use no cache holds it, and with two LDS stages a k-loop cannot cover an HBM
+        # round trip per k-tile; touched a kernel ahead, the lines wait in the memory-side cache.  A/B: RPO_NO_WPREFETCH=1.
+        pf = os.environ.get("RPO_NO_WPREFETCH") != "1" and self.act != torch.float32
+        # Every kernel names its successor's weights.  Other assignments measured same-box (profiles/README.md): naming the
+        # matrix two kernels ahead (B), or hosting nothing in c_fc (Bp / C / D), 2.92-2.95 ms against 2.908 ms; off 3.03 ms.
+        table = dict(in_="out", out="fc", fc="proj", proj="in+")
+
+        def pf_of(host: str, l: int):
+            what = table[host] if pf else None
+            if what is None:
+                return None
+            if what.endswith("+"):
+                if l >= last:
+                    return None
+                b, what = self.vis[l + 1], what[:-1]
+            else:
+                b = self.vis[l]
+            return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
+                    "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
             # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
@@ -339,7 +378,8 @@ class Engine:
             if l < last or full_last:
                 # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
                 with self._timed("in_proj"):
-                    ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv))
+                    ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv),
+                                prefetch=pf_of("in_", l))
                 with self._timed("attn_fwd"):
                     ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
                 lo = 0
@@ -363,12 +403,13 @@ class Engine:
             prod = dict(out2=h[lo:], ln_stats=so[lo:], ln_group=go) if fold else {}
             with timed("out_proj"):
                 ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:], row_units=un_o,
-                            **prod)
+                            **prod, prefetch=pf_of("out", l))
             if fold:
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                                 aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo,
-                                ln_stats=so[lo:], ln_colsum=blk.s_fc, row_units=un, ln_group=go)
+                                ln_stats=so[lo:], ln_colsum=blk.s_fc, row_units=un, ln_group=go,
+                                prefetch=pf_of("fc", l))
             else:
                 with timed("ln_2"):
                     ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
@@ -379,7 +420,7 @@ class Engine:
             prod = dict(out2=h[lo:], ln_stats=sp[lo:], ln_group=gp) if (fold and l < last) else {}
             with timed("c_proj"):
                 ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:], row_units=un_p,
-                            **prod)
+                            **prod, prefetch=pf_of("proj", l))
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 
@@ -388,11 +429,19 @@ class Engine:
                        u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd, fold_out: bool = False) -> torch.Tensor:
         """Shared by both towers: dx (fp32, in dxa) holds dL/d(block output) on entry; on return the
         tensor holding dL/d(block-0 input).  dxc mirrors dx in the act dtype (GEMM A operand)."""
+        pf = self._pf_chains
         for l in reversed(range(len(blocks))):
             blk = blocks[l]
             a_in = dxa if self.act == torch.float32 else dxc
-            ops.gemm_nt(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l])          # d c_proj, d QuickGELU
-            ops.gemm_nt(du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC)   # d c_fc
+            # prefetch hints: every dX GEMM names the weights the chain reads next (d c_proj -> w_fc_t; d c_fc -> the two
+            # d x d operands of the attention backward; d q-proj -> the next block's w_proj_t)
+            # (measured and dropped, same-box: a second hint range for what the backward re-reads from the forward pass --
+            #  the frozen rows' K / V of the block, 29 MB, named by this GEMM for the attention backward two kernels on:
+            #  step 1.8 % SLOWER, 3.045 vs 2.992 ms; the saved QuickGELU operand u[l-1], named by the d q-proj GEMM: no
+            #  effect, 2.875 vs 2.871 ms)
+            ops.gemm_nt(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None)  # d c_proj, d QuickGELU
+            ops.gemm_nt(du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC,
+                        prefetch=blk.w_oq_t if pf else None)                     # d c_fc
             ops.layernorm_bwd(dy[:SPLIT_FC], xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
@@ -401,7 +450,8 @@ class Engine:
             else:
                 ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                      # d out_proj
                 attn_bwd(l, da, dq)
-            ops.gemm_nt(dq, blk.w_q_t, dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)   # d q-projection
+            ops.gemm_nt(dq, blk.w_q_t, dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q,
+                        prefetch=blocks[l - 1].w_proj_t if (pf and l > 0) else None)   # d q-projection
             ops.layernorm_bwd(dy[:SPLIT_Q], x[l], blk.ln1_w, dxb, dxa,
                               None if self.act == torch.float32 else dxc)
         return dxa
@@ -416,7 +466,8 @@ class Engine:
             d_f = self.d_img_f[:Rp]
         else:
             d_f = self.d_img_f_a[:Rp]                  # written by the head's backward
-        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, :Rp], EPI_NONE)
+        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, :Rp], EPI_NONE,
+                    prefetch=self.vis[-1].w_proj_t if self._pf_chains else None)
         ops.layernorm_bwd(self.dy_v[0, :Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
@@ -444,7 +495,8 @@ class Engine:
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
         d_f = self.d_text_f if self.act == torch.float32 else self.d_text_f_a      # written by the head's backward
-        ops.gemm_nt(d_f, self.text_proj, self.dy_t[0], EPI_NONE)
+        ops.gemm_nt(d_f, self.text_proj, self.dy_t[0], EPI_NONE,
+                    prefetch=self.txt[-1].w_proj_t if self._pf_chains else None)
         ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 

@@ -51,7 +51,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
             group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0,
             out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
             ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS,
-            row_units: Optional[tuple] = None, ln_group: int = 0) -> torch.Tensor:
+            row_units: Optional[tuple] = None, ln_group: int = 0,
+            prefetch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
@@ -76,6 +77,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
                     out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
     args.ln_group = ln_group
+    if prefetch is not None:                # hint: what the next launch reads first (include/rpo_amd.h)
+        assert prefetch.is_contiguous()
+        args.prefetch, args.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     if aux is not None and aux.dtype != torch.float32:      # 16-bit aux: holds d quickgelu / du (include/rpo_amd.h)
         args.aux_dtype = dtype_code(aux.dtype)
     if row_units is not None:               # (rows per unit in segment 0, rows per unit in segment 1, first row of segment 1)

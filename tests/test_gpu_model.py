@@ -900,3 +900,24 @@ def test_cocoop_trainer_sgd_steps_match_oracle():
     assert set(tr.model.prompt_learner.state_dict()) == {"ctx", "meta_net.linear1.weight", "meta_net.linear1.bias",
                                                          "meta_net.linear2.weight", "meta_net.linear2.bias",
                                                          "token_prefix", "token_suffix"}
+
+
+def test_weight_prefetch_hints_do_not_change_the_step(monkeypatch):
+    """The prefetch hints of the step (every GEMM names the weights its successor reads) are
+    timing-only: two optimiser steps at the bench's shape with them and without them (RPO_NO_WPREFETCH=1) leave
+    bit-identical losses and prompts."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.trainer import RPO
+    cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 24, 32)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RPO_NO_WPREFETCH", "1")
+        else:
+            monkeypatch.delenv("RPO_NO_WPREFETCH", raising=False)
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=32, num_batches=10 ** 9, prompts=(tp, ip))
+        assert tr.engine._pf_chains == (not off)
+        losses = [tr.forward_backward({"img": torch.from_numpy(image), "label": torch.from_numpy(label)})["loss"] for _ in range(2)]
+        res.append((losses, tr.engine.params.clone()))
+        del tr
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])

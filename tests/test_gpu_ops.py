@@ -701,6 +701,43 @@ def test_head_fwd_bwd(B, C, K, e):
     close(logits, lg, "f32", "head logits (bad label)", tol=5e-6)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_gemm_prefetch_hint_changes_nothing_but_time(mode):
+    """rpo_gemm_args.prefetch (the next launch's weights, touched into the memory-side cache by every workgroup before
+    its k-loop) is a hint: every kernel that implements it -- the three one-round kernels at the bench's shapes and the
+    generic tiles, plain and split-K -- must return the bits it returns without it, for hint ranges that are larger than,
+    equal to and smaller than one line per thread, and ranges whose size is not a multiple of anything."""
+    from rpo_amd import _lib as L
+    o = ops()
+    N0, K0, units = 197, 24, 32
+    M = units * (N0 + K0)
+    ru = (N0, K0, units * N0)
+    hints = [torch.randn(n, device=dev()).to(DT[mode]) for n in (768 * 3072, 96 * 64 + 13, 257)]
+    cases = [  # (M, N, K, epilogue, extra kwargs)
+        (M, 2304, 768, L.EPI_BIAS, {}),                                              # gemm_w4
+        (M, 3072, 768, L.EPI_BIAS_QGELU, dict(row_units=ru)),                        # gemm_w4g
+        (M, 768, 3072, L.EPI_BIAS_RESID, dict(row_units=ru)),                        # gemm_w4k
+        (768, 3072, 768, L.EPI_BIAS, {}),                                            # generic 64x64
+        (768, 768, 3072, L.EPI_NONE, dict(split_k=3)),                               # generic, split-K (2-D grid)
+    ]
+    for M_, N_, K_, epi, kw in cases:
+        a, w = rnd((M_, K_), 1, 0.5).to(dev(), DT[mode]), rnd((N_, K_), 2, K_ ** -0.5).to(dev(), DT[mode])
+        kw = dict(kw)
+        if epi != L.EPI_NONE:
+            kw["bias"] = rnd((N_,), 3).to(dev())
+        if epi == L.EPI_BIAS_RESID:
+            kw["resid"] = rnd((M_, N_), 4).to(dev())
+        odt = torch.float32 if epi in (L.EPI_BIAS_RESID, L.EPI_NONE) else DT[mode]
+        shape = (kw["split_k"], M_, N_) if "split_k" in kw else (M_, N_)
+        base = torch.full(shape, float("nan"), dtype=odt, device=dev())
+        o.gemm_nt(a, w, base, epi, **kw)
+        assert torch.isfinite(base.float()).all()
+        for h in hints:
+            out = torch.full(shape, float("nan"), dtype=odt, device=dev())
+            o.gemm_nt(a, w, out, epi, prefetch=h, **kw)
+            assert torch.equal(out, base), f"prefetch hint changed the result of {M_}x{N_}x{K_} epilogue {epi}"
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,N,Kp,d", [(3, 50, 7, 768), (2, 197, 24, 768), (1, 17, 1, 1024), (2, 10, 0, 512)])
 def test_img_embed_norm_equals_assemble_plus_two_layernorms(mode, B, N, Kp, d):
