@@ -166,6 +166,27 @@ int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x
                       float* dx, int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast,
                       int rows, int d, float eps, int dy_splits, int64_t dy_split_stride, void* stream);
 
+/* rpo_gemm_nt for TWO problems in one launch: workgroups [0, tiles of a0) tile problem a0, the rest a1.  The image
+ * tower's and the text tower's prompt-row chains (autograd of trainers/rpo.py:308 through clip/model.py:181-207 for the
+ * K prompt rows of every image / class) have the same stages; issued pairwise they are ONE chain of launches on one queue.
+ * Both problems must be what rpo_gemm_nt runs on its 64x64 tiles: 16-bit inputs of one format, the same out_dtype,
+ * epilogue (NONE or QGELU_BWD) and split_k, M < 2048, tile_config 0, no skip_*; otherwise RPO_E_SHAPE / RPO_E_DTYPE and
+ * nothing is launched.  Bit-identical to two rpo_gemm_nt calls. */
+int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1, void* stream);
+
+/* rpo_layernorm_bwd for two problems in one launch (fp32 dy slabs; both casts, where present, of one dtype). */
+typedef struct rpo_ln_bwd_args {
+  const float* dy; int64_t lddy;            /* fp32 [rows, d], or dy_splits slabs dy + s * dy_split_stride */
+  const float* x; int64_t ldx;              /* the forward input, fp32 */
+  const float* gamma;
+  const float* dres; int64_t lddres;        /* fp32 or NULL */
+  float* dx; int64_t lddx;
+  void* dx_cast; int32_t cast_dtype; int64_t ldcast;   /* optional copy of dx (NULL: none) */
+  int32_t rows, d; float eps;
+  int32_t dy_splits; int64_t dy_split_stride;
+} rpo_ln_bwd_args;
+int rpo_layernorm_bwd_pair(const rpo_ln_bwd_args* a0, const rpo_ln_bwd_args* a1, void* stream);
+
 /* Non-overlapping-patch im2col: img [B,3,H,W] fp32 -> out [B*(H/p)*(W/p), ldo] act dtype, column
  * order (c, ky, kx) = conv1.weight.reshape(d, -1); columns [3*p*p, ldo) are zero-filled.
  * With rpo_gemm_nt(RPO_EPI_PATCH) this replaces the stride-p Conv2d at trainers/rpo.py:198-200. */
@@ -221,6 +242,25 @@ int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const 
 int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                const void* dx, int64_t lddx, const void* w_out_t, int64_t ldw, void* dq, int64_t lddq,
                                int dtype, int B, int H, int N, int Kp, float scale, void* stream);
+
+/* rpo_attn_readonly_bwd_proj for one problem (a1 == NULL) or two problems in ONE launch, each optionally with per-group
+ * key counts: group g (an image, or a class of the text tower) reads keys [0, key_len[g]) of the key_stride rows that
+ * k / v hold per group -- the text tower's mask (trainers/rpo.py:144-151: causal AND column < len_c) lets a prompt row of
+ * class c read exactly the len_c frozen tokens of its class, so the per-class K / V cache [n_cls * Lmax, .] is such a
+ * layout; key_len == NULL: every group has `keys` keys stored back to back (the image tower, as
+ * rpo_attn_readonly_bwd_proj).  keys <= 288 (the maximum over groups), Kp <= 32, H * 64 in {512, 768}; 16-bit dtypes.
+ * Pairs: problem 0 with 97..224 keys and d = 768, problem 1 with <= 96 keys (ViT-B/16 image tower + text tower). */
+typedef struct rpo_attn_bwd_args {
+  const void* q_rows; int64_t ldq;          /* [groups * Kp, .]: q of the back-propagated rows */
+  const void* k; const void* v; int64_t ldkv;
+  const void* dx; int64_t lddx;             /* d(out-proj output) of those rows, act dtype [groups * Kp, d] */
+  const void* w_out_t; int64_t ldw;         /* out_proj.weight transposed, [d (in), d (out)] */
+  void* dq; int64_t lddq;
+  int32_t groups, H, keys, Kp;
+  const int32_t* key_len; int32_t key_stride;
+  float scale;
+} rpo_attn_bwd_args;
+int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_attn_bwd_args* a1, int dtype, void* stream);
 
 /* Text-tower attention for `rows` query rows per class against that class's cached keys /
  * values kc, vc [n_cls * Lmax, ldkv] (class c uses rows c*Lmax .. c*Lmax + len[c]).

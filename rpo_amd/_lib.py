@@ -54,12 +54,31 @@ class GemmArgs(C.Structure):
     ]
 
 
+class LnBwdArgs(C.Structure):
+    """struct rpo_ln_bwd_args (include/rpo_amd.h)."""
+    _fields_ = [("dy", c_vp), ("lddy", c_i64), ("x", c_vp), ("ldx", c_i64), ("gamma", c_vp),
+                ("dres", c_vp), ("lddres", c_i64), ("dx", c_vp), ("lddx", c_i64),
+                ("dx_cast", c_vp), ("cast_dtype", c_i32), ("ldcast", c_i64),
+                ("rows", c_i32), ("d", c_i32), ("eps", c_f32), ("dy_splits", c_i32), ("dy_split_stride", c_i64)]
+
+
+class AttnBwdArgs(C.Structure):
+    """struct rpo_attn_bwd_args (include/rpo_amd.h)."""
+    _fields_ = [("q_rows", c_vp), ("ldq", c_i64), ("k", c_vp), ("v", c_vp), ("ldkv", c_i64),
+                ("dx", c_vp), ("lddx", c_i64), ("w_out_t", c_vp), ("ldw", c_i64), ("dq", c_vp), ("lddq", c_i64),
+                ("groups", c_i32), ("H", c_i32), ("keys", c_i32), ("Kp", c_i32),
+                ("key_len", c_vp), ("key_stride", c_i32), ("scale", c_f32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/rpo_amd.h declares
 SIGNATURES = {
     "rpo_version": (c_i32, []),
     "rpo_gemm_stats_group": (c_i32, [C.POINTER(GemmArgs)]),
     "rpo_error_string": (C.c_char_p, [c_i32]),
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
+    "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),
+    "rpo_attn_bwd_proj_pair": (c_i32, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_i32, c_vp]),
     "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                   c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i64, c_vp]),

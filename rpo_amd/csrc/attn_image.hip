@@ -443,14 +443,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
 // each, operands straight from global memory in one batch with the K / V staging loads, partial tiles summed through LDS
 // before K / V land there -- and feeds it to the dP MFMAs in the layout the result tile already has
 // (tile_times_cdfrag).  One launch and one [B*Kp, d] round trip per block less on the backward chain.
-template <typename T, int NT, int NCW = 0>
+template <typename T, int NT, int NCW>
 // (No __restrict__ on the inputs: hipcc treats loads through restrict-const pointers as invariant and moves them across
 // the asm memory barriers that pin the order of the fused prologue's loads -- its vmcnt waits are counted.)
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t ldq, const T* k, const T* v,
-                                                       int64_t ldkv, const T* da, int64_t ldda,
-                                                       T* dq, int64_t lddq, int B, int H, int N, int Kp,
-                                                       float scale, const T* wo = nullptr, int64_t ldwo = 0) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// (bid, nwg): this problem's workgroup index / count (the whole grid in a plain launch, its share of the grid in a paired
+// one).  key_len / key_stride: group b reads keys [0, key_len[b]) of the key_stride rows that k / v hold per group (the text
+// tower's per-class K / V cache: trainers/rpo.py:144-151 -- a prompt row of class c reads exactly the len_c frozen tokens);
+// key_len == nullptr: every group has N keys stored back to back (the image tower).
+__device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const int nwg,
+                                              const T* qr, int64_t ldq, const T* k, const T* v,
+                                              int64_t ldkv, const T* da, int64_t ldda,
+                                              T* dq, int64_t lddq, int B, int H, int N, int Kp,
+                                              float scale, const T* wo, int64_t ldwo,
+                                              const int32_t* key_len, int key_stride) {
   using L = AL<T, NT>;
   constexpr int stat_off = NCW > 0 && L::BWD_BYTES < 65536 ? 65536 : L::BWD_BYTES;   // launchers allocate stat_off + 2048
   const int tid = threadIdx.x, lane = tid & 63;
@@ -459,17 +464,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
   // Block bid runs on XCD bid % 8: every XCD takes a contiguous run of (image, head) pairs, i.e. whole images -- the
   // images whose rows the out-proj / c_fc / c_proj kernels around this one handle on the same XCD (row units).
 #ifdef RPO_ATTN_PLAIN_ORDER
-  const int wgid = blockIdx.x;
+  const int wgid = bid;
 #else
   const int wgid = [&] {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }();
 #endif
   const int b = wgid / H, h = wgid % H;
-  const T* kb = k + (int64_t)b * N * ldkv + h * 64;
-  const T* vb = v + (int64_t)b * N * ldkv + h * 64;
+  if (key_len != nullptr) N = max(1, min(key_len[b], min(key_stride, NT * 32)));   // keys of this group
+  else key_stride = N;
+  const T* kb = k + (int64_t)b * key_stride * ldkv + h * 64;
+  const T* vb = v + (int64_t)b * key_stride * ldkv + h * 64;
   char* ks = smem;
   char* vs = smem + L::K_BYTES;
   float4* part_u = reinterpret_cast<float4*>(smem);                 // [4 waves][8 groups][64 lanes]
@@ -722,6 +728,49 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
   }
 }
 
+template <typename T, int NT, int NCW = 0>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t ldq, const T* k, const T* v,
+                                                       int64_t ldkv, const T* da, int64_t ldda,
+                                                       T* dq, int64_t lddq, int B, int H, int N, int Kp,
+                                                       float scale, const T* wo = nullptr, int64_t ldwo = 0,
+                                                       const int32_t* key_len = nullptr, int key_stride = 0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_bwd_body<T, NT, NCW>(smem, blockIdx.x, gridDim.x, qr, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, wo,
+                            ldwo, key_len, key_stride);
+}
+
+// Two attention-backward problems (d out-proj folded in) in one launch: workgroups [0, blocks0) are the (image, head)
+// pairs of problem 0, the rest the (class, head) pairs of problem 1 -- the same stage of the two prompt-row chains.
+struct AttnBwdProblem {
+  const void* qr; int64_t ldq; const void* k; const void* v; int64_t ldkv; const void* da; int64_t ldda;
+  void* dq; int64_t lddq; int B, H, N, Kp; float scale; const void* wo; int64_t ldwo; const int32_t* key_len; int key_stride;
+};
+// Problem 1 may get fewer workgroups than it has (group, head) items (each then walks items bid, bid + wgs1, ...): the
+// kernel keeps two workgroups per CU resident, and a second round for a few dozen workgroups would double the launch.
+template <typename T, int NT0, int NCW0, int NT1, int NCW1>
+__global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const AttnBwdProblem a, const AttnBwdProblem b,
+                                                            const int blocks0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < blocks0) {
+    attn_bwd_body<T, NT0, NCW0>(smem, blockIdx.x, blocks0, static_cast<const T*>(a.qr), a.ldq, static_cast<const T*>(a.k),
+                                static_cast<const T*>(a.v), a.ldkv, static_cast<const T*>(a.da), a.ldda,
+                                static_cast<T*>(a.dq), a.lddq, a.B, a.H, a.N, a.Kp, a.scale, static_cast<const T*>(a.wo),
+                                a.ldwo, a.key_len, a.key_stride);
+  } else {
+    const int items = b.B * b.H, first = (int)blockIdx.x - blocks0, wgs1 = (int)gridDim.x - blocks0;
+    for (int t = first; t < items; t += wgs1) {
+      if (t != first) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // the previous item's partials have been read
+      }
+      attn_bwd_body<T, NT1, NCW1>(smem, t, items, static_cast<const T*>(b.qr), b.ldq, static_cast<const T*>(b.k),
+                                  static_cast<const T*>(b.v), b.ldkv, static_cast<const T*>(b.da), b.ldda,
+                                  static_cast<T*>(b.dq), b.lddq, b.B, b.H, b.N, b.Kp, b.scale, static_cast<const T*>(b.wo),
+                                  b.ldwo, b.key_len, b.key_stride);
+    }
+  }
+}
+
 template <typename T, int NT>
 int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
                int N, int Kp, float scale, int q_first, hipStream_t s) {
@@ -744,7 +793,8 @@ int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
-                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(nullptr), (int64_t)0);
+                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(nullptr), (int64_t)0,
+                     static_cast<const int32_t*>(nullptr), 0);
   return rpo_launch_status();
 }
 
@@ -758,8 +808,80 @@ int launch_bwd_proj(const void* qr, int64_t ldq, const void* k, const void* v, i
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(dx), lddx,
-                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(wo), ldwo);
+                     static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(wo), ldwo,
+                     static_cast<const int32_t*>(nullptr), 0);
   return rpo_launch_status();
+}
+
+bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
+
+constexpr int bwd_proj_lds(int bwd_bytes) { return (bwd_bytes > 65536 ? bwd_bytes : 65536) + 2048; }
+
+// one problem with per-group key counts (the text tower)
+template <typename T, int NT, int NCW>
+int launch_bwd_proj_var(const AttnBwdProblem& a, hipStream_t s) {
+  static rpo_lds_mask_t lds_ok{0};
+  auto kern = attn_bwd_kernel<T, NT, NCW>;
+  constexpr int bytes = bwd_proj_lds(AL<T, NT>::BWD_BYTES);
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(256), bytes, s, static_cast<const T*>(a.qr), a.ldq,
+                     static_cast<const T*>(a.k), static_cast<const T*>(a.v), a.ldkv, static_cast<const T*>(a.da), a.ldda,
+                     static_cast<T*>(a.dq), a.lddq, a.B, a.H, a.N, a.Kp, a.scale, static_cast<const T*>(a.wo), a.ldwo,
+                     a.key_len, a.key_stride);
+  return rpo_launch_status();
+}
+template <typename T, int NT0, int NCW0, int NT1, int NCW1>
+int launch_bwd_proj_pair(const AttnBwdProblem& a, const AttnBwdProblem& b, hipStream_t s) {
+  static rpo_lds_mask_t lds_ok{0};
+  auto kern = attn_bwd_pair_kernel<T, NT0, NCW0, NT1, NCW1>;
+  constexpr int b0 = bwd_proj_lds(AL<T, NT0>::BWD_BYTES), b1 = bwd_proj_lds(AL<T, NT1>::BWD_BYTES);
+  constexpr int bytes = b0 > b1 ? b0 : b1;
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
+  const int items0 = a.B * a.H, items1 = b.B * b.H, slots = 2 * rpo_cu_count();
+  int wgs1 = items1;
+  for (int walk = 2; items0 + wgs1 > slots && walk <= 8; ++walk) wgs1 = (items1 + walk - 1) / walk;
+  hipLaunchKernelGGL(kern, dim3(items0 + wgs1), dim3(256), bytes, s, a, b, items0);
+  return rpo_launch_status();
+}
+// (key tiles, 256-column chunks of d) of one problem; 0 if the fused kernel does not cover it
+inline int bwd_proj_geometry(const rpo_attn_bwd_args& a, int* nt, int* ncw) {
+  const int d = a.H * 64;
+  if (a.keys > 288 || a.Kp > 32 || (d != 512 && d != 768)) return 0;
+  *nt = a.keys <= 96 ? 3 : (a.keys <= 224 ? 7 : 9);
+  *ncw = d / 256;
+  return 1;
+}
+inline int bwd_proj_check(const rpo_attn_bwd_args& a) {
+  if (!a.q_rows || !a.k || !a.v || !a.dx || !a.w_out_t || !a.dq || a.groups <= 0 || a.H <= 0 || a.keys <= 0 || a.Kp <= 0)
+    return RPO_E_BADARG;
+  if (a.key_len != nullptr && a.key_stride < a.keys) return RPO_E_BADARG;
+  if (!aligned16(a.q_rows) || !aligned16(a.k) || !aligned16(a.v) || !aligned16(a.dx) || !aligned16(a.w_out_t) ||
+      !ok_ld(a.ldq, 2) || !ok_ld(a.ldkv, 2) || !ok_ld(a.lddx, 2) || !ok_ld(a.ldw, 2) ||
+      reinterpret_cast<uintptr_t>(a.dq) % 8 || (a.lddq * 2) % 8) return RPO_E_ALIGN;
+  return 0;
+}
+inline AttnBwdProblem bwd_problem(const rpo_attn_bwd_args& a) {
+  return AttnBwdProblem{a.q_rows, a.ldq, a.k, a.v, a.ldkv, a.dx, a.lddx, a.dq, a.lddq, a.groups, a.H, a.keys, a.Kp,
+                        a.scale, a.w_out_t, a.ldw, a.key_len, a.key_len ? a.key_stride : a.keys};
+}
+template <typename T>
+int dispatch_bwd_proj_args(const rpo_attn_bwd_args* a0, const rpo_attn_bwd_args* a1, hipStream_t s) {
+  int nt0, ncw0, nt1 = 0, ncw1 = 0;
+  if (!bwd_proj_geometry(*a0, &nt0, &ncw0) || (a1 && !bwd_proj_geometry(*a1, &nt1, &ncw1))) return RPO_E_SHAPE;
+  const AttnBwdProblem p0 = bwd_problem(*a0);
+  if (a1 == nullptr) {
+#define RPO_BV(NT_, NCW_) if (nt0 == NT_ && ncw0 == NCW_) return launch_bwd_proj_var<T, NT_, NCW_>(p0, s)
+    RPO_BV(3, 2); RPO_BV(3, 3); RPO_BV(7, 2); RPO_BV(7, 3); RPO_BV(9, 2); RPO_BV(9, 3);
+#undef RPO_BV
+    return RPO_E_SHAPE;
+  }
+  const AttnBwdProblem p1 = bwd_problem(*a1);
+  // the pairs a step of this repo's models forms: image tower (197 keys, d 768) with the text tower (<= 96 keys, d 512)
+#define RPO_BPAIR(A, B, C, D) if (nt0 == A && ncw0 == B && nt1 == C && ncw1 == D) return launch_bwd_proj_pair<T, A, B, C, D>(p0, p1, s)
+  RPO_BPAIR(7, 3, 3, 2);
+  RPO_BPAIR(7, 3, 3, 3);
+#undef RPO_BPAIR
+  return RPO_E_SHAPE;
 }
 template <typename T>
 int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void* k, const void* v, int64_t ldkv,
@@ -772,7 +894,6 @@ int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void
   return RPO_E_SHAPE;
 }
 
-bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
 
 }  // namespace
 
@@ -847,4 +968,16 @@ extern "C" int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const
   if (dtype == RPO_BF16)
     return dispatch_bwd_proj<bf16_t>(d / 256, N > 224, q_rows, ldq, k, v, ldkv, dx, lddx, w_out_t, ldw, dq, lddq, B, H, N, Kp, scale, s);
   return dispatch_bwd_proj<f16_t>(d / 256, N > 224, q_rows, ldq, k, v, ldkv, dx, lddx, w_out_t, ldw, dq, lddq, B, H, N, Kp, scale, s);
+}
+
+// rpo_attn_readonly_bwd_proj for one or two problems in ONE launch, each with optional per-group key counts
+// (include/rpo_amd.h: rpo_attn_bwd_args).  a1 == NULL: one problem.
+extern "C" int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_attn_bwd_args* a1, int dtype, void* stream) {
+  if (a0 == nullptr) return RPO_E_BADARG;
+  if (dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
+  if (int rc = bwd_proj_check(*a0)) return rc;
+  if (a1 != nullptr) if (int rc = bwd_proj_check(*a1)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == RPO_BF16) return dispatch_bwd_proj_args<bf16_t>(a0, a1, s);
+  return dispatch_bwd_proj_args<f16_t>(a0, a1, s);
 }

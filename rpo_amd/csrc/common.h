@@ -166,6 +166,19 @@ static inline int rpo_launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// CUs of the current device (the devices of a node are identical: asked once)
+static inline int rpo_cu_count() {
+  static std::atomic<int> cached{0};
+  int n = cached.load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  int dev = 0;
+  n = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    n = 256;
+  cached.store(n, std::memory_order_relaxed);
+  return n;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Optional in-kernel timeline (debug build with -DRPO_TIMELINE; tools/gemm_timeline.py, tools/attn_timeline.py):

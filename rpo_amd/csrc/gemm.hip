@@ -64,25 +64,28 @@ struct GemmParams {
 // Prefetch hint: this workgroup's share of the lines at pf_ptr, one dword per 128-B line and lane, REQUESTED before the
 // k-loop and consumed (by an empty asm) after it -- like the LayerNorm statistics the loads are older than every DMA of
 // the loop, so its counted vmcnt waits only get stricter, and nothing waits for them before the loop's own first wait.
-__device__ __forceinline__ uint32_t prefetch_range(const char* ptr, int64_t bytes) {
+// (bid, nwg) = this problem's workgroup index / count along x: the whole grid for a plain launch, the problem's own share
+// of it in a paired launch (rpo_gemm_nt_pair)
+__device__ __forceinline__ uint32_t prefetch_range(const char* ptr, int64_t bytes, int bid, int nwg) {
   uint32_t v = 0;
   if (ptr != nullptr) {
     const int64_t lines = bytes >> 7;
-    const int64_t nblk = (int64_t)gridDim.x * gridDim.y;              // (split-K launches are 2-D)
+    const int64_t nblk = (int64_t)nwg * gridDim.y;                    // (split-K launches are 2-D)
     const int64_t per = (lines + nblk - 1) / nblk;
-    const int64_t l0 = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * per;
+    const int64_t l0 = ((int64_t)blockIdx.y * nwg + bid) * per;
     for (int64_t i = threadIdx.x; i < per; i += blockDim.x)
       if (l0 + i < lines) v ^= *reinterpret_cast<const uint32_t*>(ptr + ((l0 + i) << 7));
   }
   return v;
 }
-__device__ __forceinline__ uint32_t prefetch_touch(const GemmParams& p) {
+__device__ __forceinline__ uint32_t prefetch_touch(const GemmParams& p, int bid, int nwg) {
 #ifndef RPO_NO_PREFETCH
-  return prefetch_range(p.pf_ptr, p.pf_bytes);
+  return prefetch_range(p.pf_ptr, p.pf_bytes, bid, nwg);
 #else
   return 0;
 #endif
 }
+__device__ __forceinline__ uint32_t prefetch_touch(const GemmParams& p) { return prefetch_touch(p, blockIdx.x, gridDim.x); }
 
 constexpr int LN_GROUP = 64;               // columns per partial LayerNorm statistic written by the generic epilogues
 
@@ -183,11 +186,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define RPO_GM 8
 #endif
 template <int BM, int BN, int GM = RPO_GM>
-__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0, const int bid, const int nwg) {
   const int tiles_n = (p.N + BN - 1) / BN;      // BM, BN are powers of two or constants: shifts / mul-shift
   int wg;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }
@@ -207,6 +209,10 @@ __device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n
   const int tile_n = fdiv(in_grp, gm);
   const int tile_m = grp * GM + (in_grp - tile_n * gm);
   m0 = tile_m * BM; n0 = tile_n * BN;
+}
+template <int BM, int BN, int GM = RPO_GM>
+__device__ __forceinline__ void tile_origin(const GemmParams& p, int& m0, int& n0) {
+  tile_origin<BM, BN, GM>(p, m0, n0, blockIdx.x, gridDim.x);
 }
 
 // The saved operand of the QuickGELU backward (rpo_gemm_args.aux / aux_dtype): either the fp32 pre-activation u (the
@@ -491,9 +497,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
+// The kernel body: workgroup `bid` of the `nwg` that tile problem p (the whole grid along x for a plain launch; a paired
+// launch gives each of its two problems a contiguous share of the grid, rpo_gemm_nt_pair).
 template <typename TIn, typename TOut, int EPI, typename CF>
-__global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_nt_body(const GemmParams& p, char* smem, const int bid, const int nwg) {
   using T = Tr<TIn>;
   constexpr int BM = CF::BM, BN = CF::BN, NSTAGE = CF::NSTAGE;
   const int tid = threadIdx.x;
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
 
   RPO_STAMP(0);
   int m0, n0;
-  tile_origin<BM, BN>(p, m0, n0);
+  tile_origin<BM, BN>(p, m0, n0, bid, nwg);
   if (p.skip_row0 >= 0 && m0 >= p.skip_row0 && n0 >= p.skip_col0) return;
 
   // k-range of this split
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
     epi_preload<EPI, CF, TIn>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
                                               // in-loop DMA, so the counted waits below stay valid (conservative)
   }
-  const uint32_t pf_touch = prefetch_touch(p);     // the same holds for the prefetch hint's loads (GemmParams::pf_ptr)
+  const uint32_t pf_touch = prefetch_touch(p, bid, nwg);   // the same holds for the prefetch hint's loads (GemmParams::pf_ptr)
 
 #ifdef RPO_TIMELINE
   unsigned long long t_wait = 0, t_bar = 0, t_body = 0, t_a, t_b, t_c, t_d;
@@ -655,6 +662,37 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RPO_STAMP(61);
+}
+
+template <typename TIn, typename TOut, int EPI, typename CF>
+__global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_body<TIn, TOut, EPI, CF>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// Two independent problems of the same kind (dtypes, epilogue, tile shape, split-K factor) in ONE launch: workgroups
+// [0, tiles0) tile problem 0, the rest problem 1.  The two prompt-row chains of a step (image tower / text tower) have the
+// same stages; launched pairwise they are one chain of kernels on one queue instead of two chains on two queues whose
+// kernels delay each other (profiles/README.md, round 3).
+// A problem may get fewer workgroups than it has tiles (its workgroups then walk tiles bid, bid + wgs, ...): the launcher
+// trims the problem with the shorter k-loop until both fit the CUs in ONE round -- a second round for a few dozen
+// workgroups doubles the duration of a launch that is one link of a latency chain.
+struct GemmPair { GemmParams p[2]; int tiles[2]; int wgs0; };
+template <typename TIn, typename TOut, int EPI, typename CF>
+__global__ __launch_bounds__(CF::THREADS) void gemm_nt_pair_kernel(const GemmPair g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int second = (int)blockIdx.x >= g.wgs0;                    // uniform
+  const int bid = second ? (int)blockIdx.x - g.wgs0 : (int)blockIdx.x;
+  const int nwg = second ? (int)gridDim.x - g.wgs0 : g.wgs0;
+  const int tiles = g.tiles[second];
+  for (int t = bid; t < tiles; t += nwg) {
+    if (t != bid) {                                                // the previous tile's stores are out, its staging image read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (second) gemm_nt_body<TIn, TOut, EPI, CF>(g.p[1], smem, t, tiles);
+    else gemm_nt_body<TIn, TOut, EPI, CF>(g.p[0], smem, t, tiles);
+  }
 }
 
 // ---- ping-pong 256x256 kernel (bf16) ---------------------------------------------------------------------
@@ -1004,7 +1042,8 @@ extern "C" int rpo_gemm_stats_group(const rpo_gemm_args* a) {
   return kgrp != 0 ? kgrp : LN_GROUP;
 }
 
-extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
+// Argument checks of rpo_gemm_nt and the kernel-side parameter block (shared with rpo_gemm_nt_pair)
+static int gemm_prepare(const rpo_gemm_args* a, GemmParams& p) {
   if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return RPO_E_BADARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return RPO_E_BADARG;
   // "bf16" below = either 16-bit storage format; a 16-bit output must have the input's format
@@ -1038,7 +1077,6 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
       (!aligned16(a->aux) || a->ldaux % 4 != 0)) return RPO_E_ALIGN;
   if (epi == RPO_EPI_PATCH && a->group <= 0) return RPO_E_BADARG;
 
-  GemmParams p;
   p.A = static_cast<const char*>(a->A); p.lda = a->lda;
   p.W = static_cast<const char*>(a->W); p.ldw = a->ldw;
   p.C = static_cast<char*>(a->C); p.ldc = a->ldc;
@@ -1063,6 +1101,15 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   if (p.seg_rows0 < 0 || p.seg_rows1 < 0 || p.seg1_row0 < 0 || p.seg1_row0 > p.M) return RPO_E_BADARG;
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
+  return 0;
+}
+
+extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
+  GemmParams p;
+  if (int rc = gemm_prepare(a, p)) return rc;
+  const bool in_f16 = a->in_dtype == RPO_F16;
+  const bool in_bf16 = a->in_dtype == RPO_BF16 || in_f16, out_bf16 = a->out_dtype == RPO_BF16 || a->out_dtype == RPO_F16;
+  const int epi = a->epilogue;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (in_f16) {
     if (out_bf16) return dispatch_epi<f16_t, f16_t>(epi, p, s);
@@ -1073,4 +1120,65 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
     return dispatch_f32out<bf16_t>(epi, p, s);
   }
   return dispatch_f32out<float>(epi, p, s);
+}
+
+// Two GEMMs in one launch (see gemm_nt_pair_kernel): the same stage of the image tower's and of the text tower's
+// prompt-row chain.  Both must be small-M problems of the same kind -- 16-bit inputs of one format, the same output
+// dtype, epilogue and split-K factor, M < 2048, tile_config 0 -- i.e. what rpo_gemm_nt would run on its 64x64 tiles;
+// anything else returns RPO_E_SHAPE / RPO_E_DTYPE (the caller then issues two rpo_gemm_nt calls).  Results are
+// bit-identical to the two separate launches.
+namespace {
+template <typename TIn, typename TOut, int EPI>
+int launch_pair(const GemmPair& g, int wgs1, int split_k, hipStream_t s) {
+  static rpo_lds_mask_t lds_ok{0};
+  using CF = CfgTiny;
+  auto kern = gemm_nt_pair_kernel<TIn, TOut, EPI, CF>;
+  constexpr int smem_bytes = CF::SMEM + CF::BM * 8;
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), smem_bytes, &lds_ok)) return rc;
+  hipLaunchKernelGGL(kern, dim3(g.wgs0 + wgs1, split_k), dim3(CF::THREADS), smem_bytes, s, g);
+  return rpo_launch_status();
+}
+template <typename TIn>
+int dispatch_pair(int epi, bool out16, const GemmPair& g, int wgs1, int split_k, hipStream_t s) {
+  if (out16) {
+    if (epi == RPO_EPI_QGELU_BWD) return launch_pair<TIn, TIn, RPO_EPI_QGELU_BWD>(g, wgs1, split_k, s);
+    if (epi == RPO_EPI_NONE) return launch_pair<TIn, TIn, RPO_EPI_NONE>(g, wgs1, split_k, s);
+    return RPO_E_SHAPE;
+  }
+  if (epi == RPO_EPI_NONE) return launch_pair<TIn, float, RPO_EPI_NONE>(g, wgs1, split_k, s);
+  return RPO_E_SHAPE;
+}
+}  // namespace
+
+extern "C" int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1, void* stream) {
+  GemmPair g;
+  if (int rc = gemm_prepare(a0, g.p[0])) return rc;
+  if (int rc = gemm_prepare(a1, g.p[1])) return rc;
+  const bool in16 = a0->in_dtype == RPO_BF16 || a0->in_dtype == RPO_F16;
+  if (!in16 || a0->in_dtype != a1->in_dtype || a0->out_dtype != a1->out_dtype) return RPO_E_DTYPE;
+  if (a0->epilogue != a1->epilogue || g.p[0].split_k != g.p[1].split_k || a0->tile_config != 0 || a1->tile_config != 0 ||
+      a0->M >= 2048 || a1->M >= 2048 || g.p[0].skip_row0 >= 0 || g.p[1].skip_row0 >= 0) return RPO_E_SHAPE;
+  using CF = CfgTiny;
+  auto tiles = [](const GemmParams& p) { return ((p.M + CF::BM - 1) / CF::BM) * ((p.N + CF::BN - 1) / CF::BN); };
+  g.tiles[0] = tiles(g.p[0]); g.tiles[1] = tiles(g.p[1]);
+  // One round: the 64x64 kernel keeps RPO_PAIR_WG_PER_CU workgroups per CU resident (48 KiB of LDS each).  If the two
+  // problems together need more, the one with the shorter k-loop gets half as many workgroups as tiles (each walks two),
+  // then a third, ... until everything is resident at once.
+#ifndef RPO_PAIR_WG_PER_CU
+#define RPO_PAIR_WG_PER_CU 3
+#endif
+  int wgs[2] = {g.tiles[0], g.tiles[1]};
+  {
+    const int cus = rpo_cu_count();
+    const int slots = RPO_PAIR_WG_PER_CU * cus / g.p[0].split_k;
+    const int shorter = g.p[0].K <= g.p[1].K ? 0 : 1;
+    for (int walk = 2; wgs[0] + wgs[1] > slots && walk <= 8; ++walk)
+      wgs[shorter] = (g.tiles[shorter] + walk - 1) / walk;
+  }
+  g.wgs0 = wgs[0];
+  const int tiles1 = wgs[1];
+  const bool out16 = a0->out_dtype != RPO_F32;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a0->in_dtype == RPO_F16) return dispatch_pair<f16_t>(a0->epilogue, out16, g, tiles1, g.p[0].split_k, s);
+  return dispatch_pair<bf16_t>(a0->epilogue, out16, g, tiles1, g.p[0].split_k, s);
 }

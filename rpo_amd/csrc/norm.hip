@@ -155,15 +155,15 @@ template <> __device__ __forceinline__ float4 load4f<f16_t>(const f16_t* p) {
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 template <typename TDY, typename TC, int NV>
-__global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
-                                                     const float* __restrict__ x, int64_t ldx,
-                                                     const float* __restrict__ gamma,
-                                                     const float* __restrict__ dres, int64_t lddres,
-                                                     float* dx, int64_t lddx, TC* dxc, int64_t ldc,
-                                                     int rows, int d, float eps, int splits,
-                                                     int64_t split_stride) {
+__device__ __forceinline__ void ln_bwd_row(const TDY* __restrict__ dy, int64_t lddy,
+                                           const float* __restrict__ x, int64_t ldx,
+                                           const float* __restrict__ gamma,
+                                           const float* __restrict__ dres, int64_t lddres,
+                                           float* dx, int64_t lddx, TC* dxc, int64_t ldc,
+                                           int rows, int d, float eps, int splits,
+                                           int64_t split_stride, const int blk) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);
+  const int row = blk * RPO_LN_RPB + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv4 = d >> 2;
   const float* xr = x + (int64_t)row * ldx;
@@ -244,6 +244,34 @@ __global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __re
   }
 }
 
+template <typename TDY, typename TC, int NV>
+__global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t lddy,
+                                                     const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ dres, int64_t lddres,
+                                                     float* dx, int64_t lddx, TC* dxc, int64_t ldc,
+                                                     int rows, int d, float eps, int splits,
+                                                     int64_t split_stride) {
+  ln_bwd_row<TDY, TC, NV>(dy, lddy, x, ldx, gamma, dres, lddres, dx, lddx, dxc, ldc, rows, d, eps, splits, split_stride,
+                          blockIdx.x);
+}
+
+// Two LayerNorm backward problems in one launch (fp32 dy slabs, the same cast dtype): blocks [0, blocks0) take the rows of
+// problem 0, the rest those of problem 1 -- the same stage of the image tower's and the text tower's prompt-row chain.
+struct LnBwdProblem {
+  const float* dy; int64_t lddy; const float* x; int64_t ldx; const float* gamma; const float* dres; int64_t lddres;
+  float* dx; int64_t lddx; void* dxc; int64_t ldc; int rows, d; float eps; int splits; int64_t split_stride;
+};
+struct LnBwdPair { LnBwdProblem p[2]; int blocks0; };
+template <typename TC, int NV>
+__global__ __launch_bounds__(64 * RPO_LN_RPB) void ln_bwd_pair_kernel(const LnBwdPair g) {
+  const int second = (int)blockIdx.x >= g.blocks0;
+  const LnBwdProblem& q = g.p[second];
+  ln_bwd_row<float, TC, NV>(q.dy, q.lddy, q.x, q.ldx, q.gamma, q.dres, q.lddres, q.dx, q.lddx, static_cast<TC*>(q.dxc),
+                            q.ldc, q.rows, q.d, q.eps, q.splits, q.split_stride,
+                            second ? (int)blockIdx.x - g.blocks0 : (int)blockIdx.x);
+}
+
 }  // namespace
 
 extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
@@ -280,10 +308,9 @@ extern "C" int rpo_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   return rpo_launch_status();
 }
 
-extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
-                                 const float* gamma, const float* dres, int64_t lddres, float* dx,
-                                 int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast, int rows,
-                                 int d, float eps, int dy_splits, int64_t dy_split_stride, void* stream) {
+static int ln_bwd_check(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                        const float* dres, int64_t lddres, float* dx, int64_t lddx, void* dx_cast, int64_t ldcast, int rows,
+                        int d, int& dy_splits, int64_t dy_split_stride) {
   if (!dy || !x || !gamma || !dx || rows <= 0 || d <= 0) return RPO_E_BADARG;
   if (d % 4 != 0 || d > 64 * 4 * MAXV) return RPO_E_SHAPE;
   if (dy_splits < 1) dy_splits = 1;
@@ -292,6 +319,46 @@ extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, con
   if (dres && (!aligned16(dres) || lddres % 4)) return RPO_E_ALIGN;
   if (dx_cast && (reinterpret_cast<uintptr_t>(dx_cast) % 8 || ldcast % 4)) return RPO_E_ALIGN;
   if (reinterpret_cast<uintptr_t>(dy) % (dy_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
+  return 0;
+}
+
+extern "C" int rpo_layernorm_bwd_pair(const rpo_ln_bwd_args* a0, const rpo_ln_bwd_args* a1, void* stream) {
+  if (!a0 || !a1) return RPO_E_BADARG;
+  LnBwdPair g;
+  int nv = 0;
+  for (int i = 0; i < 2; ++i) {
+    const rpo_ln_bwd_args* a = i ? a1 : a0;
+    int splits = a->dy_splits;
+    if (int rc = ln_bwd_check(a->dy, RPO_F32, a->lddy, a->x, a->ldx, a->gamma, a->dres, a->lddres, a->dx, a->lddx,
+                              a->dx_cast, a->ldcast, a->rows, a->d, splits, a->dy_split_stride)) return rc;
+    g.p[i] = LnBwdProblem{a->dy, a->lddy, a->x, a->ldx, a->gamma, a->dres, a->lddres, a->dx, a->lddx, a->dx_cast,
+                          a->ldcast, a->rows, a->d, a->eps, splits, a->dy_split_stride};
+    { const int n = (a->d / 4 + 63) / 64; if (n > nv) nv = n; }
+  }
+  const int cast = a0->dx_cast ? a0->cast_dtype : (a1->dx_cast ? a1->cast_dtype : RPO_F32);
+  if ((a0->dx_cast && a0->cast_dtype != cast) || (a1->dx_cast && a1->cast_dtype != cast)) return RPO_E_DTYPE;
+  if (cast != RPO_F32 && cast != RPO_BF16 && cast != RPO_F16) return RPO_E_DTYPE;
+  g.blocks0 = (a0->rows + RPO_LN_RPB - 1) / RPO_LN_RPB;
+  const dim3 grid(g.blocks0 + (a1->rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define RPO_LN_PAIR_(TC, NV) hipLaunchKernelGGL((ln_bwd_pair_kernel<TC, NV>), grid, block, 0, s, g)
+#define RPO_LN_PAIR(TC)                                                                                    \
+  do {                                                                                                     \
+    if (nv <= 2) RPO_LN_PAIR_(TC, 2); else if (nv == 3) RPO_LN_PAIR_(TC, 3);                               \
+    else if (nv == 4) RPO_LN_PAIR_(TC, 4); else RPO_LN_PAIR_(TC, 8);                                       \
+  } while (0)
+  if (cast == RPO_BF16) RPO_LN_PAIR(bf16_t); else if (cast == RPO_F16) RPO_LN_PAIR(f16_t); else RPO_LN_PAIR(float);
+#undef RPO_LN_PAIR
+#undef RPO_LN_PAIR_
+  return rpo_launch_status();
+}
+
+extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
+                                 const float* gamma, const float* dres, int64_t lddres, float* dx,
+                                 int64_t lddx, void* dx_cast, int cast_dtype, int64_t ldcast, int rows,
+                                 int d, float eps, int dy_splits, int64_t dy_split_stride, void* stream) {
+  if (int rc = ln_bwd_check(dy, dy_dtype, lddy, x, ldx, gamma, dres, lddres, dx, lddx, dx_cast, ldcast, rows, d, dy_splits,
+                            dy_split_stride)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
   const int nv = (d / 4 + 63) / 64;

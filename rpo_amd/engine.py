@@ -490,6 +490,89 @@ class Engine:
         ops.layernorm_bwd(dx, self.x_pre[Rf:R], self.ln_pre[0], None, dxb)
         ops.reduce_groups(dxb, self.g_img, B)
 
+    # ------------------------------------------------------------------ both backward chains as ONE chain of launches
+    def joint_backward_ok(self, B: Optional[int] = None) -> bool:
+        """The two prompt-row chains can be issued pairwise (one launch per stage for both towers) when both attention
+        backwards run with the d out-proj GEMM folded in: 16-bit modes, K <= 32, widths 512 / 768, <= 96 text keys.
+        Measured and NOT the default: the 64x64-tile GEMMs of the chains are bound by the CUs' LDS-DMA rate, not by
+        latency (a 64-deep k-tile of a 64x64 tile is 16 KB at the ~34 B/clk a CU's DMA path delivers = the ~480 cycles
+        per k-tile of the timeline), so a paired launch takes the SUM of its two problems' times (d c_proj pair 23.3 us
+        against 15 + 9 alone, attention pair 21.9 against 17.3 + 8.9), and what is left to gain is the second queue.
+        Same box, backward phase alone at B = 4 / 8 / 16 / 32: 0.70 / 0.71 / 0.78 / 1.02 ms paired against 0.73 / 0.73 /
+        0.78 / 0.91 ms as two chains on two streams; whole step 1.70 / 2.04 / - / 3.20 ms against 1.65 / 1.97 / - / 3.02.
+        RPO_JOINT_BWD=1 turns it on (results are bit-identical either way: tests/test_gpu_model.py)."""
+        cfg = self.cfg
+        can = (self.act != torch.float32 and cfg.K <= 32 and cfg.d_v == 768 and cfg.d_t in (512, 768)
+               and self.Lmax <= 96 and cfg.n_frozen > 96 and cfg.n_frozen <= 224
+               and os.environ.get("RPO_NO_BWD_FOLD") != "1")
+        return can and os.environ.get("RPO_JOINT_BWD") == "1"
+
+    def _joint_backward(self, B: int) -> None:
+        """_image_backward + _text_backward with every stage of the two chains in ONE launch (rpo_gemm_nt_pair,
+        rpo_layernorm_bwd_pair, rpo_attn_bwd_proj_pair): the chains have the same six stages per block, and as two
+        chains on two queues their ~150 small kernels delayed each other (backward pair 0.93 ms against 0.78 ms for the
+        image chain alone, profiles/README.md).  The arithmetic of every problem is that of the separate launches."""
+        cfg = self.cfg
+        N, K, dv, dt = cfg.n_frozen, cfg.K, cfg.d_v, cfg.d_t
+        Rf, Rp, Rt, n = B * N, B * K, self.Rt, cfg.n_cls
+        R = Rf + Rp
+        pf = self._pf_chains
+        V = dict(blocks=self.vis, x=[t[Rf:R] for t in self.x], xm=[t[Rf:R] for t in self.xm], u=[t[:Rp] for t in self.u],
+                 dxa=self.dxa_v[:Rp], dxb=self.dxb_v[:Rp], dxc=self.dxc_v[:Rp], du=self.du_v[:Rp], dq=self.dq_v[:Rp],
+                 dy=self.dy_v[:, :Rp])
+        T = dict(blocks=self.txt, x=self.xt, xm=self.xtm, u=self.ut, dxa=self.dxa_t, dxb=self.dxb_t, dxc=self.dxc_t,
+                 du=self.du_t, dq=self.dq_t, dy=self.dy_t)
+
+        def attn_args(c, l):
+            if c is V:
+                qkv = self.qkv[l]
+                return dict(q_rows=qkv[Rf:R, :dv], k=qkv[:Rf, dv:2 * dv], v=qkv[:Rf, 2 * dv:], dx=c["dxc"],
+                            w_out_t=self.vis[l].w_out_t, dq=c["dq"], groups=B, H=cfg.heads_v, keys=N, Kp=K, scale=SCALE)
+            kv = self.kv_t[l]
+            return dict(q_rows=self.qt[l], k=kv[:, :dt], v=kv[:, dt:], dx=c["dxc"], w_out_t=self.txt[l].w_out_t,
+                        dq=c["dq"], groups=n, H=cfg.heads_t, keys=self.Lmax, Kp=K, scale=SCALE, key_len=self.len_i32,
+                        key_stride=self.Lmax)
+
+        def gemm(calls):
+            if len(calls) == 2:
+                ops.gemm_nt_pair(*calls)
+            else:
+                ops.gemm_nt(**calls[0])
+
+        def ln(calls):
+            if len(calls) == 2:
+                ops.layernorm_bwd_pair(*calls)
+            else:
+                ops.layernorm_bwd(**calls[0])
+
+        # heads of the chains: d projection, then ln_post / ln_final (rpo.py:210 / :183)
+        gemm([dict(a=self.d_img_f_a[:Rp], w=self.img_proj, out=self.dy_v[0, :Rp], epilogue=EPI_NONE,
+                   prefetch=self.vis[-1].w_proj_t if pf else None),
+              dict(a=self.d_text_f_a, w=self.text_proj, out=self.dy_t[0], epilogue=EPI_NONE,
+                   prefetch=self.txt[-1].w_proj_t if pf else None)])
+        ln([dict(dy=self.dy_v[0, :Rp], x=V["x"][-1], gamma=self.ln_post[0], dres=None, dx=V["dxa"], dx_cast=V["dxc"]),
+            dict(dy=self.dy_t[0], x=self.xt[-1], gamma=self.ln_final[0], dres=None, dx=T["dxa"], dx_cast=T["dxc"])])
+        Lv, Lt = len(self.vis), len(self.txt)
+        for s_ in range(max(Lv, Lt)):
+            live = [(c, len(c["blocks"]) - 1 - s_) for c in (V, T) if len(c["blocks"]) - 1 - s_ >= 0]
+            blk = lambda c, l: c["blocks"][l]
+            # the six stages of _rows_backward, for every tower that still has a block at this depth
+            gemm([dict(a=c["dxc"], w=blk(c, l).w_proj_t, out=c["du"], epilogue=EPI_QGELU_BWD, aux=c["u"][l],
+                       prefetch=blk(c, l).w_fc_t if pf else None) for c, l in live])                       # d c_proj, d QuickGELU
+            gemm([dict(a=c["du"], w=blk(c, l).w_fc_t, out=c["dy"][:SPLIT_FC], epilogue=EPI_NONE, split_k=SPLIT_FC,
+                       prefetch=blk(c, l).w_oq_t if pf else None) for c, l in live])                       # d c_fc
+            ln([dict(dy=c["dy"][:SPLIT_FC], x=c["xm"][l], gamma=blk(c, l).ln2_w, dres=c["dxa"], dx=c["dxb"],
+                     dx_cast=c["dxc"]) for c, l in live])
+            ops.attn_bwd_proj_pair(*[attn_args(c, l) for c, l in live])                                    # d out-proj + attention
+            gemm([dict(a=c["dq"], w=blk(c, l).w_q_t, out=c["dy"][:SPLIT_Q], epilogue=EPI_NONE, split_k=SPLIT_Q,
+                       prefetch=c["blocks"][l - 1].w_proj_t if (pf and l > 0) else None) for c, l in live])  # d q-projection
+            ln([dict(dy=c["dy"][:SPLIT_Q], x=c["x"][l], gamma=blk(c, l).ln1_w, dres=c["dxb"], dx=c["dxa"],
+                     dx_cast=c["dxc"]) for c, l in live])
+        # image: through ln_pre (rpo.py:206) to the appended prompt rows; both: sum over the batch / the classes (.repeat)
+        ops.layernorm_bwd(V["dxa"], self.x_pre[Rf:R], self.ln_pre[0], None, V["dxb"])
+        ops.reduce_groups(V["dxb"], self.g_img, B)
+        ops.reduce_groups(T["dxa"], self.g_text, n)
+
     def _text_backward(self) -> None:
         cfg = self.cfg
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
@@ -500,12 +583,26 @@ class Engine:
         ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
+        # RPO_TEXT_BWD_FOLD=1 (16-bit modes, K <= 32, <= 96 keys): the MFMA attention backward of the image tower with
+        # per-class key counts and the d out-proj GEMM folded in (rpo_attn_bwd_proj_pair) instead of a GEMM + the VALU
+        # kernel.  Measured and NOT the default: the text chain alone gets 16 % shorter (583 -> 490 us) and the step 0.4 %
+        # LONGER (3.016 vs 3.003 ms at B = 32, three alternating pairs; 0 at B = 4) -- the text chain is not what the step
+        # waits for, its kernels' footprint on the CUs is, and the MFMA kernel (250 VGPRs, 66 KB of LDS per workgroup)
+        # stands in the image chain's way more than the VALU kernel + a 64x64 GEMM do.
+        fold_out = (self.act != torch.float32 and K <= 32 and dt in (512, 768) and self.Lmax <= 96
+                    and os.environ.get("RPO_NO_BWD_FOLD") != "1" and os.environ.get("RPO_TEXT_BWD_FOLD") == "1")
+
         def attn_bwd(l, da, dq):
             kv = self.kv_t[l]
-            ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
+            if fold_out:
+                ops.attn_bwd_proj_pair(dict(q_rows=self.qt[l], k=kv[:, :dt], v=kv[:, dt:], dx=da,
+                                            w_out_t=self.txt[l].w_out_t, dq=dq, groups=n, H=H, keys=self.Lmax, Kp=K,
+                                            scale=SCALE, key_len=self.len_i32, key_stride=self.Lmax))
+            else:
+                ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
 
         dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
-                                 self.dq_t, self.dy_t, attn_bwd)
+                                 self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out)
         ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
 
     # ------------------------------------------------------------------ public
@@ -796,6 +893,9 @@ class Engine:
         ops.head_fwd_bwd(self.img_f[:B * K].view(B, K, e), self.text_f.view(n, K, e), label, self.logit_scale_exp,
                          self.logits[:B], self.loss, self.d_img_f[:B * K].view(B, K, e),
                          self.d_text_f.view(n, K, e), self.head_ws, **self._head_act(B))
+        if self.joint_backward_ok(B):
+            self._joint_backward(B)
+            return
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._text_backward()

@@ -45,15 +45,15 @@ def version() -> int:
     return _lib.load().rpo_version()
 
 
-def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
+def gemm_args(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
             aux: Optional[torch.Tensor] = None, aux_row0: int = 0, skip_row0: int = -1, skip_col0: int = -1,
             group: int = 0, m_rows: Optional[int] = None, split_k: int = 1, tile_config: int = 0,
             out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
             ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS,
             row_units: Optional[tuple] = None, ln_group: int = 0,
-            prefetch: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
+            prefetch: Optional[torch.Tensor] = None) -> GemmArgs:
+    """The rpo_gemm_args of out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
     LayerNorm fold: a BIAS_RESID call may also leave ``out2`` (act-dtype copy of its result) and ``ln_stats``
@@ -88,8 +88,21 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
         rows = a.shape[0] if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else M
         cols = K if epilogue in (_lib.EPI_LN_BIAS, _lib.EPI_LN_BIAS_QGELU) else N
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= rows * (cols // (ln_group or 64)) * 2
+    return args
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> torch.Tensor:
+    """out = a @ w.T with a fused epilogue (rpo_gemm_nt); keyword arguments as `gemm_args`."""
+    args = gemm_args(a, w, out, epilogue, **kw)
     check(_lib.load().rpo_gemm_nt(C.byref(args), _stream()), "rpo_gemm_nt")
     return out
+
+
+def gemm_nt_pair(g0: dict, g1: dict) -> None:
+    """Two small-M GEMMs of the same kind in ONE launch (rpo_gemm_nt_pair): g0 / g1 are the keyword arguments of
+    `gemm_nt` (a, w, out, epilogue, ...) of the two problems."""
+    a0, a1 = gemm_args(**g0), gemm_args(**g1)
+    check(_lib.load().rpo_gemm_nt_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_gemm_nt_pair")
 
 
 def gemm_stats_group(M: int, N: int, K: int, dtype: torch.dtype, row_units: Optional[tuple]) -> int:
@@ -129,6 +142,47 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dres: 
         RPO_F32 if dx_cast is None else dtype_code(dx_cast.dtype), 0 if dx_cast is None else _ld(dx_cast),
         x.shape[0], x.shape[1], eps, splits, split_stride, _stream()), "rpo_layernorm_bwd")
     return dx
+
+
+def _ln_bwd_args(dy, x, gamma, dres, dx, dx_cast=None, eps: float = LN_EPS) -> "_lib.LnBwdArgs":
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dx.dtype == torch.float32
+    splits, split_stride = 1, 0
+    if dy.dim() == 3:
+        splits, split_stride, lddy = dy.shape[0], dy.stride(0), dy.stride(1)
+    else:
+        lddy = _ld(dy)
+    return _lib.LnBwdArgs(dy=dy.data_ptr(), lddy=lddy, x=x.data_ptr(), ldx=_ld(x), gamma=gamma.data_ptr(),
+                          dres=_p(dres), lddres=0 if dres is None else _ld(dres), dx=dx.data_ptr(), lddx=_ld(dx),
+                          dx_cast=_p(dx_cast), cast_dtype=RPO_F32 if dx_cast is None else dtype_code(dx_cast.dtype),
+                          ldcast=0 if dx_cast is None else _ld(dx_cast), rows=x.shape[0], d=x.shape[1], eps=eps,
+                          dy_splits=splits, dy_split_stride=split_stride)
+
+
+def layernorm_bwd_pair(l0: dict, l1: dict) -> None:
+    """Two `layernorm_bwd` problems (keyword arguments dy, x, gamma, dres, dx, dx_cast) in ONE launch."""
+    a0, a1 = _ln_bwd_args(**l0), _ln_bwd_args(**l1)
+    check(_lib.load().rpo_layernorm_bwd_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_layernorm_bwd_pair")
+
+
+def _attn_bwd_args(q_rows, k, v, dx, w_out_t, dq, groups: int, H: int, keys: int, Kp: int, scale: float = 0.125,
+                   key_len: Optional[torch.Tensor] = None, key_stride: int = 0) -> "_lib.AttnBwdArgs":
+    assert q_rows.dtype == k.dtype == v.dtype == dx.dtype == w_out_t.dtype == dq.dtype and _ld(k) == _ld(v)
+    if key_len is not None:
+        assert key_len.dtype == torch.int32 and key_len.is_contiguous() and key_len.numel() >= groups
+    return _lib.AttnBwdArgs(q_rows=q_rows.data_ptr(), ldq=_ld(q_rows), k=k.data_ptr(), v=v.data_ptr(), ldkv=_ld(k),
+                            dx=dx.data_ptr(), lddx=_ld(dx), w_out_t=w_out_t.data_ptr(), ldw=_ld(w_out_t),
+                            dq=dq.data_ptr(), lddq=_ld(dq), groups=groups, H=H, keys=keys, Kp=Kp,
+                            key_len=_p(key_len), key_stride=key_stride, scale=scale)
+
+
+def attn_bwd_proj_pair(p0: dict, p1: Optional[dict] = None) -> None:
+    """Attention backward of the prompt rows with the d out-proj GEMM folded in, for one or two problems in ONE launch
+    (rpo_attn_bwd_proj_pair).  p0 / p1: keyword arguments q_rows, k, v, dx, w_out_t, dq, groups, H, keys, Kp, scale and,
+    for per-group key counts (the text tower's K / V cache), key_len (int32 [groups]) + key_stride."""
+    a0 = _attn_bwd_args(**p0)
+    a1 = None if p1 is None else _attn_bwd_args(**p1)
+    check(_lib.load().rpo_attn_bwd_proj_pair(C.byref(a0), None if a1 is None else C.byref(a1),
+                                             dtype_code(p0["dq"].dtype), _stream()), "rpo_attn_bwd_proj_pair")
 
 
 def im2col_patches(img: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Tensor:

@@ -147,8 +147,13 @@ class RPO:
         self._g_text_fwd = cap(lambda: eng._text_forward(train=True))
         self._g_img_fwd = cap(lambda: eng._image_forward(self._image, train=True))
         self._g_head = cap(lambda: eng.head(B, self._label))
-        self._g_text_bwd = cap(eng._text_backward)
-        self._g_img_bwd = cap(lambda: eng._image_backward(B))
+        # both backward chains as one chain of paired launches where the kernels allow it (Engine._joint_backward)
+        self._joint_bwd = eng.joint_backward_ok(B)
+        if self._joint_bwd:
+            self._g_bwd = cap(lambda: eng._joint_backward(B))
+        else:
+            self._g_text_bwd = cap(eng._text_backward)
+            self._g_img_bwd = cap(lambda: eng._image_backward(B))
         self._ev_fork = torch.cuda.Event()
         self._ev_text_fwd = torch.cuda.Event()
         self._ev_head = torch.cuda.Event()
@@ -166,6 +171,9 @@ class RPO:
         self._g_img_fwd.replay()
         main.wait_event(self._ev_text_fwd)
         self._g_head.replay()
+        if self._joint_bwd:
+            self._g_bwd.replay()
+            return
         self._ev_head.record(main)
         side.wait_event(self._ev_head)
         with torch.cuda.stream(side):

@@ -921,3 +921,24 @@ def test_weight_prefetch_hints_do_not_change_the_step(monkeypatch):
         res.append((losses, tr.engine.params.clone()))
         del tr
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("B", [4, 32])
+def test_joint_backward_equals_the_two_chains(monkeypatch, B):
+    """Engine._joint_backward issues every stage of the image tower's and the text tower's backward chain as ONE launch
+    (rpo_gemm_nt_pair, rpo_layernorm_bwd_pair, rpo_attn_bwd_proj_pair).  Every problem of a paired launch is bit-identical
+    to its own launch, so two optimiser steps with the chains paired (RPO_JOINT_BWD=1) and as two chains on two streams
+    (the default) must leave bit-identical losses, gradients and prompts -- at the reference's batch 4 and at the bench's
+    32, where the text problem's workgroups walk several tiles."""
+    from rpo_amd.trainer import RPO
+    cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 24, 32)
+    image, label = image[:B], label[:B]
+    res = []
+    for joint in ("1", "0"):
+        monkeypatch.setenv("RPO_JOINT_BWD", joint)
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=10 ** 9, prompts=(tp, ip))
+        losses = [tr.forward_backward({"img": torch.from_numpy(image), "label": torch.from_numpy(label)})["loss"] for _ in range(2)]
+        assert tr._joint_bwd == (joint == "1")
+        res.append((losses, tr.engine.grads.clone(), tr.engine.params.clone()))
+        del tr
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

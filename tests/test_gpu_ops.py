@@ -635,6 +635,120 @@ def test_attn_readonly_bwd_with_out_proj_folded_in(mode, B, H, N, Kp):
             o.attn_readonly_bwd_proj(big, t[:Rf, d:2 * d], t[:Rf, 2 * d:], big, w_t, big.clone(), B, H, N, 33)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("H,lens,Kr,Lmax", [(8, [3, 71, 20, 8, 10, 77, 1], 24, 77), (12, [5, 96, 33], 7, 96), (8, [9, 4], 32, 20)])
+def test_text_attn_bwd_with_out_proj_folded_in(mode, H, lens, Kr, Lmax):
+    """rpo_attn_bwd_proj_pair with ONE problem and per-group key counts: the text tower's attention backward (per-class
+    K / V cache, trainers/rpo.py:144-151) on the image tower's MFMA kernel with the d out-proj GEMM folded in.  Against
+    float64 and against the GEMM + VALU-kernel pair it replaces; rows of the cache past len_c hold garbage (NaN) that
+    must never be read into the result."""
+    from rpo_amd import _lib as L
+    o = ops()
+    n, d, dt = len(lens), 64 * H, DT[mode]
+    kv = rnd((n * Lmax, 2 * d), 31)
+    qr, dx, w_out = rnd((n * Kr, d), 32, 1.5), rnd((n * Kr, d), 33), rnd((d, d), 34, d ** -0.5)
+    kvd = kv.to(dev(), dt)
+    kv_poison = kvd.clone()
+    for c, Lc in enumerate(lens):
+        kv_poison[c * Lmax + Lc:(c + 1) * Lmax] = float("nan")
+    len_d = torch.tensor(lens, dtype=torch.int32, device=dev())
+    w_t = w_out.t().contiguous().to(dev(), dt)
+    prob = lambda kvt, dq: dict(q_rows=qr.to(dev(), dt), k=kvt[:, :d], v=kvt[:, d:], dx=dx.to(dev(), dt), w_out_t=w_t, dq=dq,
+                                groups=n, H=H, keys=Lmax, Kp=Kr, scale=0.125, key_len=len_d, key_stride=Lmax)
+    dq = torch.full((n * Kr, d), float("nan"), dtype=dt, device=dev())
+    o.attn_bwd_proj_pair(prob(kv_poison, dq))
+    assert bool(torch.isfinite(dq.float()).all()), "rows past len_c leaked into the result"
+    da = torch.empty((n * Kr, d), dtype=dt, device=dev())
+    o.gemm_nt(dx.to(dev(), dt), w_t, da, L.EPI_NONE)
+    dq2 = torch.full((n * Kr, d), float("nan"), dtype=dt, device=dev())
+    o.text_attn_bwd(qr.to(dev(), dt), kvd[:, :d], kvd[:, d:], da, dq2, len_d, n, Kr, Lmax, H)
+    kv64, q64 = q(kv, mode), q(qr, mode)
+    da64 = q((q(dx, mode) @ q(w_out, mode)).float(), mode)
+    ref = torch.empty(n * Kr, d, dtype=torch.float64)
+    for c, Lc in enumerate(lens):
+        sl = slice(c * Kr, (c + 1) * Kr)
+        ref[sl] = R.attn_rows_bwd(q64[sl], kv64[c * Lmax:c * Lmax + Lc, :d], kv64[c * Lmax:c * Lmax + Lc, d:], da64[sl], H)
+    close(dq, ref, mode, f"text attn bwd + d out-proj H{H} K{Kr}", tol=3e-2)
+    close(dq, dq2.double().cpu(), mode, "fused vs GEMM + text attn bwd", tol=3e-2)
+    for _ in range(5):
+        dq3 = torch.empty_like(dq)
+        o.attn_bwd_proj_pair(prob(kvd, dq3))
+        assert torch.equal(dq3, dq), "not deterministic / depends on the rows past len_c"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_paired_launches_equal_the_two_separate_launches(mode):
+    """rpo_gemm_nt_pair / rpo_layernorm_bwd_pair / rpo_attn_bwd_proj_pair: one launch for the same stage of the image
+    tower's and the text tower's prompt-row chain.  Every problem must come out bit-identical to its own launch (shapes of
+    the B = 32 step: 768 rows x 768 / 3072 and 456 rows x 512 / 2048)."""
+    from rpo_amd import _lib as L
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    dt = DT[mode]
+    D = lambda t: t.to(dev(), dt)
+    shapes = [(768, 768), (456, 512)]                      # (rows, d) of the two chains
+    # -- GEMMs: d c_proj + QuickGELU' (16-bit out), split-K d c_fc and d q-proj (fp32 slabs) --------------------------
+    for epi, split, kmul, nmul, odt in ((L.EPI_QGELU_BWD, 1, 1, 4, dt), (L.EPI_NONE, 3, 4, 1, torch.float32),
+                                        (L.EPI_NONE, 2, 1, 1, torch.float32), (L.EPI_NONE, 1, 1, 1, torch.float32)):
+        calls, singles = [], []
+        for i, (M, d) in enumerate(shapes):
+            K, N = d * kmul, d * nmul
+            a, w = D(rnd((M, K), 40 + i)), D(rnd((N, K), 42 + i, K ** -0.5))
+            aux = D(rnd((M, N), 44 + i)) if epi == L.EPI_QGELU_BWD else None
+            mk = lambda: torch.full((split, M, N) if split > 1 else (M, N), float("nan"), dtype=odt, device=dev())
+            pf = D(rnd((64, 64), 46))
+            kw = dict(a=a, w=w, epilogue=epi, aux=aux, split_k=split, prefetch=pf)
+            out_p, out_s = mk(), mk()
+            calls.append(dict(out=out_p, **kw)); singles.append(dict(out=out_s, **kw))
+        o.gemm_nt_pair(*calls)
+        for c, s_ in zip(calls, singles):
+            o.gemm_nt(**s_)
+            assert torch.equal(c["out"], s_["out"]), f"paired GEMM epi {epi} split {split} differs from its own launch"
+    with pytest.raises(RPOLibraryError):                    # different epilogues cannot share a launch
+        bad = dict(calls[1]); bad["epilogue"] = L.EPI_QGELU_BWD; bad["aux"] = D(rnd((456, 512), 47))
+        o.gemm_nt_pair(calls[0], bad)
+    # -- LayerNorm backward ------------------------------------------------------------------------------------------
+    calls, singles = [], []
+    for i, (M, d) in enumerate(shapes):
+        dy, x = rnd((3, M, d), 50 + i).to(dev()), rnd((M, d), 52 + i, 2.0).to(dev())
+        g, dres = rnd((d,), 54 + i).to(dev()), rnd((M, d), 56 + i).to(dev())
+        mk = lambda: dict(dx=torch.full((M, d), float("nan"), device=dev()),
+                          dx_cast=torch.full((M, d), float("nan"), dtype=dt, device=dev()))
+        kw = dict(dy=dy[:2 + i], x=x, gamma=g, dres=dres if i == 0 else None)
+        calls.append(dict(**kw, **mk())); singles.append(dict(**kw, **mk()))
+    o.layernorm_bwd_pair(*calls)
+    for c, s_ in zip(calls, singles):
+        o.layernorm_bwd(**s_)
+        assert torch.equal(c["dx"], s_["dx"]) and torch.equal(c["dx_cast"], s_["dx_cast"]), "paired ln_bwd differs"
+    # -- attention backward + d out-proj: image problem (197 keys, d 768) with text problem (per-class key counts, d 512)
+    # (B = 32: 384 + 152 workgroups exceed the 512 resident ones, so the text problem's workgroups walk two items each)
+    for B in (4, 32):
+        _paired_attention_case(o, dt, D, B)
+
+
+def _paired_attention_case(o, dt, D, B):
+    N, Kp, n, Lmax = 197, 24, 19, 77
+    lens = torch.tensor([(7 * c) % 70 + 5 for c in range(n)], dtype=torch.int32, device=dev())
+    qkv = D(_img_rows(B, N, Kp, 768, 60))
+    Rf = B * N
+    img = lambda dq: dict(q_rows=qkv[Rf:, :768], k=qkv[:Rf, 768:1536], v=qkv[:Rf, 1536:], dx=D(rnd((B * Kp, 768), 61)),
+                          w_out_t=D(rnd((768, 768), 62, 768 ** -0.5)), dq=dq, groups=B, H=12, keys=N, Kp=Kp, scale=0.125)
+    kv, qt = D(rnd((n * Lmax, 1024), 63)), D(rnd((n * Kp, 512), 64))
+    txt = lambda dq: dict(q_rows=qt, k=kv[:, :512], v=kv[:, 512:], dx=D(rnd((n * Kp, 512), 65)),
+                          w_out_t=D(rnd((512, 512), 66, 512 ** -0.5)), dq=dq, groups=n, H=8, keys=Lmax, Kp=Kp, scale=0.125,
+                          key_len=lens, key_stride=Lmax)
+    mk = lambda r, d: torch.full((r, d), float("nan"), dtype=dt, device=dev())
+    dqi, dqt, dqi2, dqt2 = mk(B * Kp, 768), mk(n * Kp, 512), mk(B * Kp, 768), mk(n * Kp, 512)
+    o.attn_bwd_proj_pair(img(dqi), txt(dqt))
+    o.attn_bwd_proj_pair(img(dqi2))
+    o.attn_bwd_proj_pair(txt(dqt2))
+    assert torch.equal(dqi, dqi2) and torch.equal(dqt, dqt2), "paired attention backward differs from the single launches"
+    dqi3 = mk(B * Kp, 768)
+    a = img(dqi3)
+    o.attn_readonly_bwd_proj(a["q_rows"], a["k"], a["v"], a["dx"], a["w_out_t"], dqi3, B, 12, N, Kp)
+    assert torch.equal(dqi, dqi3), "rpo_attn_bwd_proj_pair differs from rpo_attn_readonly_bwd_proj"
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 def test_text_attn_fwd_bwd(mode):
     o = ops()
