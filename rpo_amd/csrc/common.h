@@ -132,14 +132,29 @@ __device__ __forceinline__ float4 quick_gelu4(float4 v) {
 // write-back lines so that the end-of-kernel flush has nothing left to write.  Measured: the producers do not get
 // shorter and the consumer of the tile then reads it from HBM (attention 13.7 -> 16.6 us after a streamed qkv): +0.7 %
 // step time.  Plain stores are what keeps a layer's hand-offs in L2 / MALL.
+// RPO_SC1_STORE (experiment): write-THROUGH stores (sc1) -- the line stays valid in this XCD's L2 for a consumer on the
+// same XCD, but is not left dirty, so the end-of-kernel release has nothing to write back.
 template <typename V>
 __device__ __forceinline__ void store_out16(V* dst, const V v) {
-#ifdef RPO_NT_STORE
+#if defined(RPO_SC1_STORE)
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_wt;
+  static_assert(sizeof(V) == 16, "16-byte stores only");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(__builtin_bit_cast(u32x4_wt, v)) : "memory");
+#elif defined(RPO_NT_STORE)
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
   static_assert(sizeof(V) == 16, "16-byte stores only");
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(dst));
 #else
   *dst = v;
+#endif
+}
+
+__device__ __forceinline__ void store_out8(void* dst, const uint2 v) {
+#if defined(RPO_SC1_STORE)
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_wt;
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(__builtin_bit_cast(u32x2_wt, v)) : "memory");
+#else
+  *reinterpret_cast<uint2*>(dst) = v;
 #endif
 }
 

@@ -174,6 +174,10 @@ using CfgBig = Cfg<2, 4, 4, 2, 2, RPO_SPREAD_BIG>;
 using CfgQuad = Cfg<2, 2, 2, 2, 2, RPO_SPREAD_QUAD>;                  // 128x128, 4 waves
 using CfgTiny = Cfg<2, 2, 1, 1, RPO_TINY_STAGES, RPO_SPREAD_TINY>;    // 64x64, 4 waves
 using CfgTall = Cfg<2, 4, 1, 1, RPO_TALL_STAGES, RPO_SPREAD_TALL>;    // 64x128, 8 waves
+// (Measured and dropped for the prompt-row chains, round 3: 128x64 and 64x128 tiles with 8 waves and 3 stages -- 24 KB of
+//  LDS-DMA per k-tile for twice the MACs of a 64x64 tile -- are 5-15 % SLOWER than 64x64 on every chain shape (d c_proj
+//  768x3072x768: 12.6 vs 12.0 us; text c_proj 456x512x2048: 15.4 vs 13.1 us): fewer workgroups than CUs.  They win
+//  only at M = 1768, i.e. the image forward of a batch of 8 (c_fc 16.9 vs 22.2 us).)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -980,6 +984,10 @@ int launch(const GemmParams& p, hipStream_t s) {
 #ifndef RPO_TINY_MAXN
 #define RPO_TINY_MAXN (1 << 30)
 #endif
+  // ... except wide, short-K outputs from 1024 rows on (in-proj / c_fc of the image forward at a batch of 5 .. 9): 64x128
+  // tiles with 8 waves, bit-identical (c_fc at M = 1768: 17.2 vs 22.2 us; the long-K c_proj stays on 64x64: 25 vs 31 us)
+  if (p.force_cfg == 0 && p.M >= 1024 && p.M < 2048 && p.N >= 1536 && p.K <= 1024 && p.split_k == 1)
+    return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
   if (p.force_cfg == 5 || (p.force_cfg == 0 && p.M < 2048 && p.N <= RPO_TINY_MAXN)) return launch_cfg<TIn, TOut, EPI, CfgTiny>(p, s);
 #ifndef RPO_TALL_N
 #define RPO_TALL_N 1024

@@ -33,6 +33,13 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("txt_q", 456, 512, 512, EPI_BIAS, torch.bfloat16, 1),
     ("txt_fc", 456, 2048, 512, EPI_BIAS_QGELU, torch.bfloat16, 1),
     ("txt_proj", 456, 512, 2048, EPI_BIAS_RESID, torch.float32, 1),
+    # the image forward at small batches (M = B * 221): every GEMM on the small-M tiles
+    ("b4_qkv", 884, 2304, 768, EPI_BIAS, torch.bfloat16, 1),
+    ("b4_out", 884, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
+    ("b4_fc", 884, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("b4_proj", 884, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
+    ("b8_fc", 1768, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("b8_proj", 1768, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
 ]
 for name, M, N, K, epi, odt, split in SHAPES:
     if ONLY is not None and name != ONLY:
