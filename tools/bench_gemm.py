@@ -40,6 +40,12 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("b4_proj", 884, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
     ("b8_fc", 1768, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
     ("b8_proj", 1768, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
+    ("b8_qkv", 1768, 2304, 768, EPI_BIAS, torch.bfloat16, 1),
+    ("b8_out", 1768, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
+    ("b16_qkv", 3536, 2304, 768, EPI_BIAS, torch.bfloat16, 1),
+    ("b16_out", 3536, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
+    ("b16_fc", 3536, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("b16_proj", 3536, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
 ]
 for name, M, N, K, epi, odt, split in SHAPES:
     if ONLY is not None and name != ONLY:
@@ -53,8 +59,8 @@ for name, M, N, K, epi, odt, split in SHAPES:
     kw = dict(bias=bias if epi in (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID) else None,
               resid=resid if epi == EPI_BIAS_RESID else None,
               aux=aux if epi in (EPI_QGELU_BWD,) else None, split_k=split)
-    if M == 7072 and os.environ.get("BENCH_NO_UNITS") != "1":
-        kw["row_units"] = (197, 24, 6304)              # the image tower's layout: one image = 197 frozen + 24 prompt rows
+    if M % 221 == 0 and M >= 1768 and os.environ.get("BENCH_NO_UNITS") != "1":
+        kw["row_units"] = (197, 24, 197 * (M // 221))              # the image tower's layout: one image = 197 frozen + 24 prompt rows
     res = []
     cfgs = [int(c) for c in os.environ.get('BENCH_CFGS', '').split(',') if c] if (ONLY is not None or 'BENCH_CFGS' in os.environ) else [2, 5, 6]
     for cfg in [0] + cfgs:
