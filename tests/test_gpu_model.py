@@ -934,6 +934,9 @@ def test_joint_backward_equals_the_two_chains(monkeypatch, B):
     cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 24, 32)
     image, label = image[:B], label[:B]
     res = []
+    # (the paired form runs the text tower's attention backward on the MFMA kernel with d out-proj folded in: the two-chain
+    #  run is given the same kernel, RPO_TEXT_BWD_FOLD=1, so that the comparison is launch structure only)
+    monkeypatch.setenv("RPO_TEXT_BWD_FOLD", "1")
     for joint in ("1", "0"):
         monkeypatch.setenv("RPO_JOINT_BWD", joint)
         tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=10 ** 9, prompts=(tp, ip))
