@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 3
+#define RPO_ABI_VERSION 4
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -132,6 +132,18 @@ typedef struct rpo_gemm_args {
      memory-side cache instead of HBM.  Kernels that do not implement the hint ignore it. */
   const void* prefetch;
   int64_t prefetch_bytes;
+  /* Residual stream as 16-bit hi / lo halves (BIAS_RESID, 16-bit inputs, optional; ABI 4).  The fp32 residual stream of
+     a transformer block (clip/model.py:188-190: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))) is written and re-read in
+     full by every residual GEMM, next to the 16-bit copy the following GEMM consumes.  With these fields the stream lives
+     as hi = round16(v) -- which IS that copy (out2) -- and lo = round16(v - hi): resid_hi / resid_lo replace `resid` as
+     the input (both or neither; leading dimension ldr16, in elements), out_lo receives lo next to out2 (leading dimension
+     ldout2), and the fp32 C is stored only for rows >= c_row0 (the back-propagated rows, whose LayerNorm backward reads
+     fp32; pass 0 to store all rows).  hi + lo carries 16 mantissa bits (bf16) / 22 (fp16) of the fp32 value.  In place is
+     allowed (resid_hi == out2, resid_lo == out_lo: every element is read and written by the same thread).  Only the
+     one-round row-unit kernels implement it: rpo_gemm_hilo_ok() tells; anything else returns RPO_E_SHAPE. */
+  const void* resid_hi; const void* resid_lo; int64_t ldr16;
+  void* out_lo;
+  int32_t c_row0;
 } rpo_gemm_args;
 
 int rpo_version(void);
@@ -148,6 +160,10 @@ int rpo_gemm_nt(const rpo_gemm_args* args, void* stream);
  * dtypes, split_k and seg_* are looked at.  Callers size ln_stats as [M, N / group, 2] floats and pass the same group to
  * the producer and to the LN_BIAS* consumer. */
 int rpo_gemm_stats_group(const rpo_gemm_args* args);
+
+/* 1 if rpo_gemm_nt would run these shapes / dtypes / row units on a kernel that implements the hi / lo residual stream
+ * (resid_hi, resid_lo, out_lo, c_row0 above), else 0.  Looks at the same fields as rpo_gemm_stats_group plus ln_group. */
+int rpo_gemm_hilo_ok(const rpo_gemm_args* args);
 
 /* y = LayerNorm(x) * gamma + beta, statistics in fp32, eps as given (1e-5).
  * x fp32 [rows, d] (ldx), y in y_dtype.  d % 4 == 0, d <= 2048.  In-place (y == x, fp32) is allowed.

@@ -51,6 +51,9 @@ class GemmArgs(C.Structure):
         ("ln_group", c_i32),
         ("aux_dtype", c_i32),
         ("prefetch", c_vp), ("prefetch_bytes", c_i64),
+        ("resid_hi", c_vp), ("resid_lo", c_vp), ("ldr16", c_i64),
+        ("out_lo", c_vp),
+        ("c_row0", c_i32),
     ]
 
 
@@ -74,6 +77,7 @@ class AttnBwdArgs(C.Structure):
 SIGNATURES = {
     "rpo_version": (c_i32, []),
     "rpo_gemm_stats_group": (c_i32, [C.POINTER(GemmArgs)]),
+    "rpo_gemm_hilo_ok": (c_i32, [C.POINTER(GemmArgs)]),
     "rpo_error_string": (C.c_char_p, [c_i32]),
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),

@@ -59,6 +59,9 @@ struct GemmParams {
   int seg_rows0, seg_rows1, seg1_row0;      // tiling hint: see include/rpo_amd.h
   int ln_group;                             // columns per partial LayerNorm statistic (64, or 96: gemm_w4k.inc)
   const char* pf_ptr; int64_t pf_bytes;     // prefetch hint (include/rpo_amd.h)
+  // residual stream as 16-bit hi / lo halves (include/rpo_amd.h): inputs, lo output next to out2, first row with fp32 C
+  const char* resid_hi; const char* resid_lo; int64_t ldr16;
+  char* out_lo; int c_row0;
 };
 
 // Prefetch hint: this workgroup's share of the lines at pf_ptr, one dword per 128-B line and lane, REQUESTED before the
@@ -937,6 +940,7 @@ int launch(const GemmParams& p, hipStream_t s) {
     if (k_ok && (p.force_cfg == 11 || p.force_cfg == 0)) return launch_w4k<TIn>(p, s);
     if (p.force_cfg == 11 || (p.ln_stats != nullptr && p.ln_group != LN_GROUP)) return RPO_E_SHAPE;
   }
+  if (p.resid_hi != nullptr || p.out_lo != nullptr || p.c_row0 > 0) return RPO_E_SHAPE;   // only the kernel above implements hi / lo
   // measured (tools/bench_gemm.py, profiles/): 256x256 wins for the wide-N forward GEMMs of the image tower
   // (in-proj 31.6 vs 36.1 us); a 4-stage 128x128 variant was slower than 2 stages on every shape
   constexpr bool big_ok = sizeof(TIn) == 2 && sizeof(TOut) == 2 &&
@@ -1078,8 +1082,18 @@ static int gemm_prepare(const rpo_gemm_args* a, GemmParams& p) {
     if (a->ln_stats != nullptr && reinterpret_cast<uintptr_t>(a->ln_stats) % 8 != 0) return RPO_E_ALIGN;
   }
   if (needs_bias && (a->bias == nullptr || !aligned16(a->bias))) return RPO_E_BADARG;
-  if ((epi == RPO_EPI_BIAS_RESID || epi == RPO_EPI_PATCH) &&
+  const bool hilo_in = a->resid_hi != nullptr || a->resid_lo != nullptr;
+  if (hilo_in || a->out_lo != nullptr || a->c_row0 != 0) {
+    if (epi != RPO_EPI_BIAS_RESID || !in_bf16 || out_bf16) return RPO_E_BADARG;
+    if (hilo_in && (a->resid_hi == nullptr || a->resid_lo == nullptr || (a->ldr16 * 2) % 8 != 0 ||
+                    reinterpret_cast<uintptr_t>(a->resid_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(a->resid_lo) % 8 != 0))
+      return RPO_E_ALIGN;
+    if (a->out_lo != nullptr && (a->out2 == nullptr || reinterpret_cast<uintptr_t>(a->out_lo) % 8 != 0)) return RPO_E_BADARG;
+    if (a->c_row0 < 0 || a->c_row0 > a->M) return RPO_E_BADARG;
+  }
+  if ((epi == RPO_EPI_BIAS_RESID || epi == RPO_EPI_PATCH) && !hilo_in &&
       (a->resid == nullptr || !aligned16(a->resid) || a->ldr % 4 != 0 || out_bf16)) return RPO_E_BADARG;
+  if (hilo_in && out_bf16) return RPO_E_BADARG;
   if (epi == RPO_EPI_QGELU_BWD && a->aux == nullptr) return RPO_E_BADARG;
   if ((epi == RPO_EPI_QGELU_BWD || ((epi == RPO_EPI_BIAS_QGELU || epi == RPO_EPI_LN_BIAS_QGELU) && a->aux != nullptr)) &&
       (!aligned16(a->aux) || a->ldaux % 4 != 0)) return RPO_E_ALIGN;
@@ -1101,6 +1115,8 @@ static int gemm_prepare(const rpo_gemm_args* a, GemmParams& p) {
   p.ln_stats = a->ln_stats; p.ln_colsum = a->ln_colsum; p.ln_eps = a->ln_eps;
   p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
   p.ln_group = a->ln_group == 0 ? LN_GROUP : a->ln_group;
+  p.resid_hi = static_cast<const char*>(a->resid_hi); p.resid_lo = static_cast<const char*>(a->resid_lo);
+  p.ldr16 = a->ldr16; p.out_lo = static_cast<char*>(a->out_lo); p.c_row0 = a->c_row0;
   p.pf_ptr = static_cast<const char*>(a->prefetch);
   p.pf_bytes = a->prefetch == nullptr ? 0 : a->prefetch_bytes;
   if (p.pf_bytes < 0 || (p.pf_ptr != nullptr && reinterpret_cast<uintptr_t>(p.pf_ptr) % 4 != 0)) return RPO_E_BADARG;
@@ -1110,6 +1126,21 @@ static int gemm_prepare(const rpo_gemm_args* a, GemmParams& p) {
   if (p.split_k > 1 && (epi != RPO_EPI_NONE || out_bf16 || p.split_k > p.K / bk || p.split_stride % 4 != 0))
     return RPO_E_SHAPE;
   return 0;
+}
+
+extern "C" int rpo_gemm_hilo_ok(const rpo_gemm_args* a) {
+  if (a == nullptr || a->M <= 0 || a->N <= 0 || a->K <= 0) return 0;
+  const bool in16 = a->in_dtype == RPO_BF16 || a->in_dtype == RPO_F16;
+  if (a->epilogue != RPO_EPI_BIAS_RESID || !in16 || a->out_dtype != RPO_F32 || a->split_k > 1 ||
+      (a->tile_config != 0 && a->tile_config != 11)) return 0;
+  GemmParams p{};
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw;
+  p.seg_rows0 = a->seg_rows0; p.seg_rows1 = a->seg_rows1; p.seg1_row0 = a->seg1_row0;
+  W4KPlan q;
+  const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 31) && (int64_t)p.N * p.ldw * 2 < (1ll << 31);
+  const int kgrp = fits32 ? w4k_plan(p, &q) : 0;
+  const int want = a->ln_group == 0 ? LN_GROUP : a->ln_group;
+  return kgrp != 0 && a->ldc % 4 == 0 && want == kgrp ? 1 : 0;
 }
 
 extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
@@ -1165,7 +1196,8 @@ extern "C" int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1
   const bool in16 = a0->in_dtype == RPO_BF16 || a0->in_dtype == RPO_F16;
   if (!in16 || a0->in_dtype != a1->in_dtype || a0->out_dtype != a1->out_dtype) return RPO_E_DTYPE;
   if (a0->epilogue != a1->epilogue || g.p[0].split_k != g.p[1].split_k || a0->tile_config != 0 || a1->tile_config != 0 ||
-      a0->M >= 2048 || a1->M >= 2048 || g.p[0].skip_row0 >= 0 || g.p[1].skip_row0 >= 0) return RPO_E_SHAPE;
+      a0->M >= 2048 || a1->M >= 2048 || g.p[0].skip_row0 >= 0 || g.p[1].skip_row0 >= 0 || g.p[0].resid_hi != nullptr ||
+      g.p[1].resid_hi != nullptr || g.p[0].out_lo != nullptr || g.p[1].out_lo != nullptr) return RPO_E_SHAPE;
   using CF = CfgTiny;
   auto tiles = [](const GemmParams& p) { return ((p.M + CF::BM - 1) / CF::BM) * ((p.N + CF::BN - 1) / CF::BN); };
   g.tiles[0] = tiles(g.p[0]); g.tiles[1] = tiles(g.p[1]);

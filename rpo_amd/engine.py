@@ -182,6 +182,7 @@ class Engine:
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
         self.h = a(R, dv)
+        self.h_lo = a(R, dv)                         # lo half of the residual stream (hi / lo mode: _image_forward)
         self.ln_stats = f32(R, dv // 64, 2)          # per-row partial LayerNorm statistics of the tensor self.h copies
         self.qkv = [a(R, 3 * dv) for _ in range(Lv)]
         self.att = a(R, dv)
@@ -341,6 +342,15 @@ class Engine:
             grps = self._stats_group[B] = ((ops.gemm_stats_group(R, dv, dv, self.act, u_out),
                                             ops.gemm_stats_group(R, dv, 4 * dv, self.act, u_proj)) if fold else (64, 64))
         g_out, g_proj = grps                 # statistics written by out-proj (read by c_fc) / by c_proj (read by in-proj)
+        # Residual stream as 16-bit hi / lo halves (rpo_gemm_args.resid_hi ...): where both residual GEMMs of a block run on
+        # the one-round row-unit kernel, the stream of the whole-batch blocks lives in h (hi = the 16-bit copy the next
+        # GEMM consumes anyway) + h_lo, updated in place; the fp32 tensors x[l] / xm[l] are then written for the prompt
+        # rows only (what the backward and ln_post read).  -10.9 MB of stores per residual GEMM.  Not when the last
+        # block's frozen rows are wanted in fp32 (full_last: forward_plain reads the CLS rows).  A/B: RPO_NO_HILO=1.
+        hilo = (fold and not full_last and u_out is not None and u_proj is not None and len(self.vis) > 1
+                and os.environ.get("RPO_NO_HILO") != "1"
+                and ops.gemm_hilo_ok(R, dv, dv, self.act, u_out, g_out) and ops.gemm_hilo_ok(R, dv, 4 * dv, self.act, u_proj, g_proj))
+        h_lo = self.h_lo[:R]
         stv = lambda grp: self.ln_stats.view(-1)[:R * (dv // grp) * 2].view(R, dv // grp, 2)
         st_out, st_proj, st64 = stv(g_out), stv(g_proj), self.ln_stats[:R]
         last = len(self.vis) - 1
@@ -401,9 +411,14 @@ class Engine:
             un = units if whole else None
             # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
             prod = dict(out2=h[lo:], ln_stats=so[lo:], ln_group=go) if fold else {}
+            # hi / lo stream: block 0's out-proj still reads the fp32 x[0] (img_embed_norm wrote it) and starts the halves
+            hl = hilo and whole
+            res_o = dict(resid_hi=h, resid_lo=h_lo) if (hl and l > 0) else dict(resid=x[lo:])
+            if hl:
+                prod.update(out_lo=h_lo, c_row0=Rf)
             with timed("out_proj"):
-                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, resid=x[lo:], row_units=un_o,
-                            **prod, prefetch=pf_of("out", l))
+                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
+                            **res_o, **prod, prefetch=pf_of("out", l))
             if fold:
                 with timed("c_fc"):
                     ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
@@ -418,9 +433,12 @@ class Engine:
                                 aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo, row_units=un)
             # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
             prod = dict(out2=h[lo:], ln_stats=sp[lo:], ln_group=gp) if (fold and l < last) else {}
+            res_p = dict(resid_hi=h, resid_lo=h_lo) if hl else dict(resid=xm[lo:])
+            if hl:
+                prod.update(out_lo=h_lo, c_row0=Rf)
             with timed("c_proj"):
-                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm[lo:], row_units=un_p,
-                            **prod, prefetch=pf_of("proj", l))
+                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
+                            **res_p, **prod, prefetch=pf_of("proj", l))
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

@@ -52,7 +52,8 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int
             out2: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
             ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = LN_EPS,
             row_units: Optional[tuple] = None, ln_group: int = 0,
-            prefetch: Optional[torch.Tensor] = None) -> GemmArgs:
+            prefetch: Optional[torch.Tensor] = None, resid_hi: Optional[torch.Tensor] = None,
+            resid_lo: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, c_row0: int = 0) -> GemmArgs:
     """The rpo_gemm_args of out = a @ w.T with a fused epilogue.  For EPI_PATCH ``out`` is the token matrix
     (more rows than ``a``); ``m_rows`` overrides M otherwise taken from ``a``.  With
     ``split_k`` = S > 1, ``out`` is [S, M, N] fp32 slabs to be summed by the consumer.
@@ -77,6 +78,13 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int
                     out2=_p(out2), ldout2=0 if out2 is None else _ld(out2), ln_stats=_p(ln_stats),
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
     args.ln_group = ln_group
+    if resid_hi is not None:                # residual stream as 16-bit hi / lo halves (include/rpo_amd.h)
+        assert resid_lo is not None and resid_hi.dtype == resid_lo.dtype == a.dtype and _ld(resid_hi) == _ld(resid_lo)
+        args.resid_hi, args.resid_lo, args.ldr16 = resid_hi.data_ptr(), resid_lo.data_ptr(), _ld(resid_hi)
+    if out_lo is not None:
+        assert out2 is not None and out_lo.dtype == out2.dtype and _ld(out_lo) == _ld(out2)
+        args.out_lo = out_lo.data_ptr()
+    args.c_row0 = c_row0
     if prefetch is not None:                # hint: what the next launch reads first (include/rpo_amd.h)
         assert prefetch.is_contiguous()
         args.prefetch, args.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
@@ -117,6 +125,19 @@ def gemm_stats_group(M: int, N: int, K: int, dtype: torch.dtype, row_units: Opti
     if g < 0:
         check(g, "rpo_gemm_stats_group")
     return g
+
+
+def gemm_hilo_ok(M: int, N: int, K: int, dtype: torch.dtype, row_units: Optional[tuple], ln_group: int = 0) -> bool:
+    """Would a BIAS_RESID GEMM of these shapes run on a kernel that implements the hi / lo residual stream
+    (rpo_gemm_hilo_ok)?"""
+    if dtype == torch.float32:
+        return False
+    args = GemmArgs(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, in_dtype=dtype_code(dtype), out_dtype=_lib.RPO_F32,
+                    epilogue=_lib.EPI_BIAS_RESID, split_k=1)
+    args.ln_group = ln_group
+    if row_units is not None:
+        args.seg_rows0, args.seg_rows1, args.seg1_row0 = row_units
+    return int(_lib.load().rpo_gemm_hilo_ok(C.byref(args))) == 1
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor,

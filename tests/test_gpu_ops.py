@@ -54,7 +54,7 @@ def test_library_loads_and_probe_layouts():
     """The fragment layouts every MFMA kernel assumes, checked on the device with an
     ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
     o = ops()
-    assert o.version() == 3
+    assert o.version() == 4
     for which, kdim in ((0, 16), (1, 2)):
         g = torch.Generator().manual_seed(which)
         a = torch.randint(-4, 5, (32, kdim), generator=g).float()
@@ -372,6 +372,55 @@ def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
         close(outs[0], R.qgelu(pre), mode, "LN-folded c_fc from 96-column statistics", tol=1.5 * TOL[mode])
         for y in outs[1:]:
             assert torch.equal(y, outs[0])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("n0,n1,units,N,K", [(197, 24, 32, 768, 768), (197, 24, 32, 768, 3072), (257, 24, 16, 1024, 1024)])
+def test_gemm_residual_stream_as_hi_lo_halves(mode, n0, n1, units, N, K):
+    """rpo_gemm_args.resid_hi / resid_lo / out_lo / c_row0: the residual stream of the one-round residual GEMMs as two
+    16-bit halves.  With a residual that IS exactly hi + lo the result must equal the fp32-residual launch bit for bit
+    (C on the rows >= c_row0, out2, statistics); rows below c_row0 of C stay untouched; out2 + out_lo reproduces the fp32
+    value to the 16 (bf16) / 21 (fp16) mantissa bits two halves carry; in place (resid_hi == out2, resid_lo == out_lo)
+    gives the same bits; kernels that do not implement it refuse."""
+    from rpo_amd import _lib as L
+    from rpo_amd._lib import RPOLibraryError
+    o = ops()
+    seg1 = n0 * units
+    M = seg1 + n1 * units
+    hint = (n0, n1, seg1)
+    dt = DT[mode]
+    grp = 96 if N == 768 else 64
+    a, w, bias = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    r32 = rnd((M, N), 4, 2.0) + 0.4
+    hi = r32.to(dt)
+    lo = (r32 - hi.float()).to(dt)
+    resid = hi.float() + lo.float()                 # exactly representable: what the halves decode to
+    assert o.gemm_hilo_ok(M, N, K, dt, hint, grp) and not o.gemm_hilo_ok(M, N, K, dt, None, grp)
+    ad, wd, bd = a.to(dev(), dt), w.to(dev(), dt), bias.to(dev())
+
+    def outs():
+        return (torch.full((M, N), float("nan"), device=dev()), torch.full((M, N), float("nan"), dtype=dt, device=dev()),
+                torch.full((M, N // grp, 2), float("nan"), device=dev()))
+    c, c2, st = outs()
+    o.gemm_nt(ad, wd, c, L.EPI_BIAS_RESID, bias=bd, resid=resid.to(dev()), out2=c2, ln_stats=st, row_units=hint, ln_group=grp)
+    ch, c2h, sth = outs()
+    clo = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+    o.gemm_nt(ad, wd, ch, L.EPI_BIAS_RESID, bias=bd, resid_hi=hi.to(dev()), resid_lo=lo.to(dev()), out2=c2h, out_lo=clo,
+              c_row0=seg1, ln_stats=sth, row_units=hint, ln_group=grp)
+    assert torch.equal(ch[seg1:], c[seg1:]) and torch.equal(c2h, c2) and torch.equal(sth, st)
+    assert bool(torch.isnan(ch[:seg1]).all()), "rows below c_row0 of C must not be written"
+    rec = c2h.float() + clo.float()
+    # (fp16: lo of a small value is a subnormal, resolution 6e-8)
+    bound = c.abs() * (2.0 ** -15 if mode == "bf16" else 2.0 ** -19) + (0.0 if mode == "bf16" else 6e-8)
+    assert bool(((rec - c).abs() <= bound).all()), f"hi + lo off by {((rec - c).abs() - bound).max().item():.2e} beyond the bound"
+    # in place: the halves of the input are overwritten by the halves of the output
+    hh, ll = hi.to(dev()).clone(), lo.to(dev()).clone()
+    cp, _, stp = outs()
+    o.gemm_nt(ad, wd, cp, L.EPI_BIAS_RESID, bias=bd, resid_hi=hh, resid_lo=ll, out2=hh, out_lo=ll, c_row0=seg1,
+              ln_stats=stp, row_units=hint, ln_group=grp)
+    assert torch.equal(hh, c2h) and torch.equal(ll, clo) and torch.equal(cp[seg1:], ch[seg1:]) and torch.equal(stp, sth)
+    with pytest.raises(RPOLibraryError):            # the generic tiles do not implement it
+        o.gemm_nt(ad, wd, outs()[0], L.EPI_BIAS_RESID, bias=bd, resid_hi=hi.to(dev()), resid_lo=lo.to(dev()))
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
