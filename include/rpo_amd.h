@@ -136,8 +136,9 @@ typedef struct rpo_gemm_args {
      a transformer block (clip/model.py:188-190: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))) is written and re-read in
      full by every residual GEMM, next to the 16-bit copy the following GEMM consumes.  With these fields the stream lives
      as hi = round16(v) -- which IS that copy (out2) -- and lo = round16(v - hi): resid_hi / resid_lo replace `resid` as
-     the input (both or neither; leading dimension ldr16, in elements), out_lo receives lo next to out2 (leading dimension
-     ldout2), and the fp32 C is stored only for rows >= c_row0 (the back-propagated rows, whose LayerNorm backward reads
+     the input (leading dimension ldr16, in elements; resid_lo may be NULL: the stream is then the 16-bit hi alone, which
+     is what the reference's own `PREC: fp16` run keeps -- clip/model.py:379-400 converts the model, :153-159 casts
+     LayerNorm's fp32 result back), out_lo receives lo next to out2 (leading dimension ldout2; NULL: not kept), and the fp32 C is stored only for rows >= c_row0 (the back-propagated rows, whose LayerNorm backward reads
      fp32; pass 0 to store all rows).  hi + lo carries 16 mantissa bits (bf16) / 22 (fp16) of the fp32 value.  In place is
      allowed (resid_hi == out2, resid_lo == out_lo: every element is read and written by the same thread).  Only the
      one-round row-unit kernels implement it: rpo_gemm_hilo_ok() tells; anything else returns RPO_E_SHAPE. */

@@ -1085,7 +1085,7 @@ static int gemm_prepare(const rpo_gemm_args* a, GemmParams& p) {
   const bool hilo_in = a->resid_hi != nullptr || a->resid_lo != nullptr;
   if (hilo_in || a->out_lo != nullptr || a->c_row0 != 0) {
     if (epi != RPO_EPI_BIAS_RESID || !in_bf16 || out_bf16) return RPO_E_BADARG;
-    if (hilo_in && (a->resid_hi == nullptr || a->resid_lo == nullptr || (a->ldr16 * 2) % 8 != 0 ||
+    if (hilo_in && (a->resid_hi == nullptr || (a->ldr16 * 2) % 8 != 0 ||
                     reinterpret_cast<uintptr_t>(a->resid_hi) % 8 != 0 || reinterpret_cast<uintptr_t>(a->resid_lo) % 8 != 0))
       return RPO_E_ALIGN;
     if (a->out_lo != nullptr && (a->out2 == nullptr || reinterpret_cast<uintptr_t>(a->out_lo) % 8 != 0)) return RPO_E_BADARG;

@@ -79,8 +79,8 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int
                     ln_colsum=_p(ln_colsum), ln_eps=ln_eps)
     args.ln_group = ln_group
     if resid_hi is not None:                # residual stream as 16-bit hi / lo halves (include/rpo_amd.h)
-        assert resid_lo is not None and resid_hi.dtype == resid_lo.dtype == a.dtype and _ld(resid_hi) == _ld(resid_lo)
-        args.resid_hi, args.resid_lo, args.ldr16 = resid_hi.data_ptr(), resid_lo.data_ptr(), _ld(resid_hi)
+        assert resid_hi.dtype == a.dtype and (resid_lo is None or (resid_lo.dtype == a.dtype and _ld(resid_hi) == _ld(resid_lo)))
+        args.resid_hi, args.resid_lo, args.ldr16 = resid_hi.data_ptr(), _p(resid_lo), _ld(resid_hi)
     if out_lo is not None:
         assert out2 is not None and out_lo.dtype == out2.dtype and _ld(out_lo) == _ld(out2)
         args.out_lo = out_lo.data_ptr()
