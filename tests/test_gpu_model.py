@@ -387,8 +387,10 @@ def test_full_size_properties(model, K, B, act):
     """BASELINE.json configs[1], [3] and every point of the configs[4] K sweep at FULL size (all layers, the bench's
     batch), where the CPU oracle is too slow to be the checker: size-independent properties of the step, and the
     throughput mode against the exact-f32 mode of the same engine (which tests/ pin to the reference at small depth).
-    These are the shapes bench.py runs, i.e. the tile selections (256x256 ping-pong in-proj at M = 7072 / 4496,
-    128x128 c_fc, 64x128 out-proj ...) are compared at model level here."""
+    These are the shapes bench.py runs, i.e. the kernels the heuristics select there -- the one-wave-per-SIMD 256x256
+    in-proj, the one-round 224x384 c_fc and 224x96 (ViT-L/14: 288x256 / 288x64) out-proj / c_proj with the hi / lo
+    residual stream, the generic tiles at K = 48 -- are compared at model level here (and against the reference's own
+    outputs in test_full_size_matches_reference_golden)."""
     from rpo_amd.config import vit_b16, vit_l14
     from rpo_amd.trainer import RPO
     cfg = (vit_b16 if model == "ViT-B/16" else vit_l14)(K=K)
