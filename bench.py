@@ -400,8 +400,11 @@ def main() -> None:
     if sync.world_size > 1:
         # ONE generation of the 150 M synthetic weights per node (local rank 0; the others memory-map its file) instead
         # of one numpy RNG pass per rank -- eight of them on one host's cores is most of the start-up time of an N = 8 run
+        # in a PRIVATE directory (mkdtemp, mode 0700, unpredictable name) made by rank 0 and announced to the others:
+        # a fixed name in the world-writable temp dir could be pre-planted as a symlink (advisor finding, round 3)
         import tempfile
-        shared = os.path.join(tempfile.gettempdir(), f"rpo_amd_weights_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}.npy")
+        shared_dir = sync.broadcast_object(tempfile.mkdtemp(prefix="rpo_amd_weights_") if sync.rank == 0 else None)
+        shared = os.path.join(shared_dir, "weights.npy")
         sd = synth.clip_state_dict_shared(cfg, 0, token_rows, shared, writer=sync.local_writer, barrier=sync.barrier)
     else:
         sd = synth.clip_state_dict(cfg, seed=0, token_rows=token_rows)
@@ -412,11 +415,8 @@ def main() -> None:
     if shared is not None:
         sync.barrier()                                   # every rank has packed its weights into HBM
         if sync.local_writer:
-            for fn in (shared, shared + ".json"):
-                try:
-                    os.remove(fn)
-                except OSError:
-                    pass
+            import shutil
+            shutil.rmtree(shared_dir, ignore_errors=True)
 
     # synthetic batches resident in HBM before the timed region (distinct data per rank and step)
     pool = 4

@@ -39,14 +39,18 @@ class GradSync:
         # kernels launch on the current device).  A lone process keeps whatever device the caller chose -- a trainer
         # built for cuda:1 must not be silently re-pointed at cuda:0.
         self.in_launcher = "LOCAL_RANK" in os.environ
-        if (self.enabled or self.in_launcher) and torch.cuda.is_available() and torch.cuda.device_count() > self.local_rank:
+        # (RPO_FORCE_DIST=1 in a lone process is NOT a distributed run: the collective path runs on whatever device the
+        #  caller chose; advisor finding, round 3)
+        self.pins_device = self.world_size > 1 or self.in_launcher
+        if self.pins_device and torch.cuda.is_available() and torch.cuda.device_count() > self.local_rank:
             torch.cuda.set_device(self.local_rank)
         if self.enabled and init and not dist.is_initialized():
             if backend is None:
                 backend = os.environ.get("RPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "nccl":
+            if backend == "nccl" and self.pins_device:
                 torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 
     def _pg(self) -> None:
@@ -93,6 +97,15 @@ class GradSync:
             self._pg()
             dist.broadcast(t, src=src)
         return t
+
+    def broadcast_object(self, obj, src: int = 0):
+        """A small picklable object from rank `src` to every rank (start-up plumbing: a private directory name)."""
+        if self.enabled:
+            self._pg()
+            box = [obj if self.rank == src else None]
+            dist.broadcast_object_list(box, src=src)
+            return box[0]
+        return obj
 
     def max_over_ranks(self, value: float, device) -> float:
         t = torch.tensor([value], dtype=torch.float64, device=device)

@@ -483,18 +483,28 @@ class Engine:
         return dxa
 
     def _image_backward(self, B: int) -> None:
+        self._image_backward_rows(B, 0, B)
+        self._image_backward_finish(B)
+
+    def _image_backward_rows(self, B: int, b0: int, b1: int) -> None:
+        """The image tower's prompt-row chain for images [b0, b1) of a batch of B: every back-propagated row depends only
+        on rows of its own image (the K / V it reads belong to frozen tokens), so any split of the batch gives independent
+        chains over disjoint row ranges of the same buffers (RPO.step_async runs them on separate streams:
+        RPO_BWD_PARTS).  Leaves dL/d(ln_pre input) of those rows in dxb_v; _image_backward_finish sums over the batch."""
         cfg = self.cfg
         N, K, dv, H = cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
-        Rf, Rp = B * N, B * K
-        R = Rf + Rp
-        dxa, dxb, dxc = self.dxa_v[:Rp], self.dxb_v[:Rp], self.dxc_v[:Rp]
+        Rf = B * N
+        r0, r1 = b0 * K, b1 * K                          # prompt-row range of the part
+        f0, f1 = b0 * N, b1 * N                          # its images' frozen rows (keys / values)
+        nb = b1 - b0
+        dxa, dxb, dxc = self.dxa_v[r0:r1], self.dxb_v[r0:r1], self.dxc_v[r0:r1]
         if self.act == torch.float32:
-            d_f = self.d_img_f[:Rp]
+            d_f = self.d_img_f[r0:r1]
         else:
-            d_f = self.d_img_f_a[:Rp]                  # written by the head's backward
-        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, :Rp], EPI_NONE,
+            d_f = self.d_img_f_a[r0:r1]                # written by the head's backward
+        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, r0:r1], EPI_NONE,
                     prefetch=self.vis[-1].w_proj_t if self._pf_chains else None)
-        ops.layernorm_bwd(self.dy_v[0, :Rp], self.x[-1][Rf:R], self.ln_post[0], None, dxa,
+        ops.layernorm_bwd(self.dy_v[0, r0:r1], self.x[-1][Rf + r0:Rf + r1], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
         # 16-bit modes, K <= 32, d = 512 / 768: the d out-proj GEMM runs inside the attention backward kernel
@@ -504,17 +514,21 @@ class Engine:
         def attn_bwd(l, da, dq):
             qkv = self.qkv[l]
             if fold_out:
-                ops.attn_readonly_bwd_proj(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da,
-                                           self.vis[l].w_out_t, dq, B, H, N, K, SCALE)
+                ops.attn_readonly_bwd_proj(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da,
+                                           self.vis[l].w_out_t, dq, nb, H, N, K, SCALE)
             else:
-                ops.attn_readonly_bwd(qkv[Rf:R, :dv], qkv[:Rf, dv:2 * dv], qkv[:Rf, 2 * dv:], da, dq, B, H, N, K, SCALE)
+                ops.attn_readonly_bwd(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da, dq,
+                                      nb, H, N, K, SCALE)
 
-        dx = self._rows_backward(self.vis, [t[Rf:R] for t in self.x[:-1]], [t[Rf:R] for t in self.xm],
-                                 [t[:Rp] for t in self.u], dxa, dxb, dxc, self.du_v[:Rp], self.da_v[:Rp],
-                                 self.dq_v[:Rp], self.dy_v[:, :Rp], attn_bwd, fold_out=fold_out)
-        # through ln_pre (rpo.py:206) to the appended prompt rows, then sum over the batch (.repeat, :204)
-        ops.layernorm_bwd(dx, self.x_pre[Rf:R], self.ln_pre[0], None, dxb)
-        ops.reduce_groups(dxb, self.g_img, B)
+        dx = self._rows_backward(self.vis, [t[Rf + r0:Rf + r1] for t in self.x[:-1]], [t[Rf + r0:Rf + r1] for t in self.xm],
+                                 [t[r0:r1] for t in self.u], dxa, dxb, dxc, self.du_v[r0:r1], self.da_v[r0:r1],
+                                 self.dq_v[r0:r1], self.dy_v[:, r0:r1], attn_bwd, fold_out=fold_out)
+        # through ln_pre (rpo.py:206) to the appended prompt rows
+        ops.layernorm_bwd(dx, self.x_pre[Rf + r0:Rf + r1], self.ln_pre[0], None, dxb)
+
+    def _image_backward_finish(self, B: int) -> None:
+        """sum over the batch (.repeat, rpo.py:204)"""
+        ops.reduce_groups(self.dxb_v[:B * self.cfg.K], self.g_img, B)
 
     # ------------------------------------------------------------------ both backward chains as ONE chain of launches
     def joint_backward_ok(self, B: Optional[int] = None) -> bool:

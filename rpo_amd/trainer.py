@@ -149,11 +149,24 @@ class RPO:
         self._g_head = cap(lambda: eng.head(B, self._label))
         # both backward chains as one chain of paired launches where the kernels allow it (Engine._joint_backward)
         self._joint_bwd = eng.joint_backward_ok(B)
+        self._bwd_parts = 1
         if self._joint_bwd:
             self._g_bwd = cap(lambda: eng._joint_backward(B))
         else:
             self._g_text_bwd = cap(eng._text_backward)
-            self._g_img_bwd = cap(lambda: eng._image_backward(B))
+            # RPO_BWD_PARTS = P > 1: the image tower's prompt-row chain as P independent chains over B / P images each, on
+            # P streams (Engine._image_backward_rows: the rows of different images never meet before the batch sum)
+            P = int(os.environ.get("RPO_BWD_PARTS", "1"))
+            self._bwd_parts = P if (P > 1 and B % P == 0) else 1
+            if self._bwd_parts > 1:
+                per = B // self._bwd_parts
+                self._g_img_bwd_parts = [cap(lambda i=i: eng._image_backward_rows(B, i * per, (i + 1) * per))
+                                         for i in range(self._bwd_parts)]
+                self._g_img_bwd_fin = cap(lambda: eng._image_backward_finish(B))
+                self._part_streams = [torch.cuda.Stream(device=self.device) for _ in range(self._bwd_parts - 1)]
+                self._ev_parts = [torch.cuda.Event() for _ in range(self._bwd_parts - 1)]
+            else:
+                self._g_img_bwd = cap(lambda: eng._image_backward(B))
         self._ev_fork = torch.cuda.Event()
         self._ev_text_fwd = torch.cuda.Event()
         self._ev_head = torch.cuda.Event()
@@ -179,7 +192,18 @@ class RPO:
         with torch.cuda.stream(side):
             self._g_text_bwd.replay()
             self._ev_text_bwd.record(side)
-        self._g_img_bwd.replay()
+        if self._bwd_parts > 1:
+            for st, ev, g in zip(self._part_streams, self._ev_parts, self._g_img_bwd_parts[1:]):
+                st.wait_event(self._ev_head)
+                with torch.cuda.stream(st):
+                    g.replay()
+                    ev.record(st)
+            self._g_img_bwd_parts[0].replay()
+            for ev in self._ev_parts:
+                main.wait_event(ev)
+            self._g_img_bwd_fin.replay()
+        else:
+            self._g_img_bwd.replay()
         main.wait_event(self._ev_text_bwd)
 
     def forward_backward(self, batch) -> Dict[str, float]:
@@ -315,62 +339,76 @@ _CKPT_ALLOWED = {
     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
     ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
     ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
-    ("torch.optim.sgd", "SGD"), ("torch.optim.optimizer", "Optimizer"),
     ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
     ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
 }
-_CKPT_ALLOWED_PREFIX = (("torch.optim.lr_scheduler", None),)      # every scheduler class of torch (plain data holders)
 
 
 class _Inert:
-    """Stand-in for classes of un-vendored packages (dassl.optim.lr_scheduler.*) met while unpickling a reference
-    checkpoint: takes any state, does nothing."""
+    """Stand-in for the optimiser / scheduler OBJECTS met while unpickling a reference checkpoint (the un-vendored
+    dassl.optim.lr_scheduler.* wrappers, torch.optim.lr_scheduler.* successors and the torch.optim.* optimiser they
+    hold): takes any constructor arguments and any state, does nothing.  Only `state_dict`, `epoch` and `optimizer`
+    (a plain dict) of a checkpoint are read, so nothing needs these objects alive."""
     def __init__(self, *a, **k):
         pass
 
+    def __call__(self, *a, **k):
+        return None
+
     def __setstate__(self, state):
         self.__dict__.update(state if isinstance(state, dict) else {})
+
+
+import pickle as _pickle
+
+
+class _RestrictedUnpickler(_pickle.Unpickler):
+    """Resolves ONLY: the exact (module, name) pairs of _CKPT_ALLOWED; torch dtypes and typed-storage classes; and maps
+    everything under `dassl` and `torch.optim` (optimisers, schedulers, and whatever those modules re-export, e.g.
+    functools.partial) to the inert stand-in.  Dotted names are refused outright: pickle protocol 4 resolves
+    `a.b` by a getattr chain, which would reach `types.FunctionType` through any allowed module that imports `types`
+    (advisor finding, round 3)."""
+
+    def find_class(self, module, name):
+        if "." in name or not name:
+            raise _pickle.UnpicklingError(f"{module}.{name} is not allowed in a checkpoint (dotted name)")
+        top = module.split(".")[0]
+        if top == "dassl" or module == "torch.optim" or module.startswith("torch.optim."):
+            return _Inert
+        key_mod = "builtins" if module == "__builtin__" else module        # protocol-2 spelling
+        ok = (key_mod, name) in _CKPT_ALLOWED
+        if not ok and module == "torch":
+            obj = getattr(torch, name, None)
+            # dtypes and the legacy typed-storage classes torch.save names in persistent ids
+            ok = isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage"))
+        if not ok:
+            raise _pickle.UnpicklingError(f"{module}.{name} is not allowed in a checkpoint")
+        return super().find_class(module, name)
+
+
+class _RestrictedPickle:                           # the `pickle_module` protocol torch.load expects
+    __name__ = "rpo_amd_restricted_pickle"
+    Unpickler = _RestrictedUnpickler
+    load = staticmethod(lambda f, **k: _RestrictedUnpickler(f, **k).load())
 
 
 def load_checkpoint_file(path: str) -> dict:
     """torch.load restricted to what a checkpoint needs.  First `weights_only=True` (tensors, numbers, plain containers:
     every file this package writes).  A file written by the reference's own Dassl run holds the cosine scheduler object
     and through it the optimiser (see _CKPT_ALLOWED), which torch's weights-only unpickler cannot rebuild even when
-    allow-listed (it refuses SETITEMS on the optimiser's defaultdict state); such files go through a restricted
-    `pickle.Unpickler` that resolves ONLY the names in _CKPT_ALLOWED, torch's storage types / dtypes and
-    torch.optim.lr_scheduler classes, maps `dassl.*` classes (un-vendored) to an inert stand-in and refuses everything
-    else -- no arbitrary callables.  Only `state_dict`, `epoch`, `optimizer` are read afterwards.
-    RPO_TRUST_CHECKPOINT=1: full unpickle for files holding anything else."""
-    import pickle
+    allow-listed (it refuses SETITEMS on the optimiser's defaultdict state); such files go through
+    _RestrictedUnpickler: an exact allow-list of data types, optimiser / scheduler classes replaced by an inert
+    stand-in, everything else -- and every dotted name -- refused.  Only `state_dict`, `epoch`, `optimizer` are read
+    afterwards.  RPO_TRUST_CHECKPOINT=1: full unpickle for files holding anything else."""
+    pickle = _pickle
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError as err:
         if os.environ.get("RPO_TRUST_CHECKPOINT") == "1":
             return torch.load(path, map_location="cpu", weights_only=False)
         first = err
-
-    class _U(pickle.Unpickler):
-        def find_class(self, module, name):
-            top = module.split(".")[0]
-            if top == "dassl":
-                return _Inert
-            key_mod = "builtins" if module == "__builtin__" else module        # protocol-2 spelling
-            ok = (key_mod, name) in _CKPT_ALLOWED or any(module == m for m, _ in _CKPT_ALLOWED_PREFIX)
-            if not ok and module == "torch":
-                obj = getattr(torch, name, None)
-                # dtypes and the legacy typed-storage classes torch.save names in persistent ids
-                ok = isinstance(obj, torch.dtype) or (isinstance(obj, type) and name.endswith("Storage"))
-            if not ok:
-                raise pickle.UnpicklingError(f"{module}.{name} is not allowed in a checkpoint")
-            return super().find_class(module, name)
-
-    class _P:                                      # the `pickle_module` protocol torch.load expects
-        __name__ = "rpo_amd_restricted_pickle"
-        Unpickler = _U
-        load = staticmethod(lambda f, **k: _U(f, **k).load())
-
     try:
-        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_P)
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_RestrictedPickle)
     except pickle.UnpicklingError as err:
         raise pickle.UnpicklingError(
             f"{path}: {err} (weights-only attempt: {str(first).splitlines()[-3] if str(first).count(chr(10)) > 2 else first}); "

@@ -181,7 +181,8 @@ def test_committed_reference_checkpoint_fixture_layout():
         ck = load_checkpoint_file(os.path.join(d, name))
         assert ck["epoch"] == 2 and {"text_prompt", "img_prompt", "token_prefix", "token_suffix"} == set(ck["state_dict"])
         succ = ck["scheduler"]["successor"]
-        assert type(succ) is torch.optim.lr_scheduler.CosineAnnealingLR and succ.T_max == 15
+        # the scheduler / optimiser objects come back as inert data holders (nothing needs them alive)
+        assert type(succ).__name__ == "_Inert" and succ.T_max == 15 and type(succ.optimizer).__name__ == "_Inert"
         assert ck["scheduler"]["warmup_epoch"] == 1 and ck["scheduler"]["cons_lr"] == 1e-5
         assert set(ck["optimizer"]["state"]) == {0, 1}
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_d1_k4.npz")))
@@ -228,6 +229,62 @@ def test_checkpoint_loader_refuses_arbitrary_callables(tmp_path, monkeypatch):
     ck = load_checkpoint_file(f2)
     assert ck["epoch"] == 4 and torch.equal(ck["state_dict"]["text_prompt"], torch.ones(2, 3))
     assert type(ck["scheduler"]).__name__ == "_Inert" and ck["scheduler"].warmup_epoch == 1
+
+
+def _torch_zip_with_pickle(path, payload: bytes):
+    """A torch-zip checkpoint whose data.pkl is `payload` (hand-written pickle opcodes)."""
+    import io
+    import zipfile
+    buf = io.BytesIO()
+    torch.save({"epoch": 1}, buf)
+    src = zipfile.ZipFile(io.BytesIO(buf.getvalue()))
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as dst:
+        for item in src.infolist():
+            data = src.read(item.filename)
+            dst.writestr(item.filename, payload if item.filename.endswith("data.pkl") else data)
+
+
+def test_checkpoint_loader_refuses_dotted_names_and_reexported_callables(tmp_path, monkeypatch):
+    """Advisor finding (round 3): pickle protocol 4 resolves a dotted name by a getattr chain, so
+    GLOBAL('torch.optim.lr_scheduler', 'types.FunctionType') reached types.FunctionType through a module the old prefix
+    rule allowed, and the un-dotted `partial` (functools.partial, re-exported there) passed too.  Now: dotted names are
+    refused; everything under torch.optim resolves to the inert stand-in, whose call does nothing."""
+    import pickle
+    from rpo_amd.trainer import _Inert, _RestrictedUnpickler, load_checkpoint_file
+    import io
+    monkeypatch.delenv("RPO_TRUST_CHECKPOINT", raising=False)
+    marker = tmp_path / "pwned"
+    u = _RestrictedUnpickler(io.BytesIO(b""))
+    for mod, name in (("torch.optim.lr_scheduler", "types.FunctionType"), ("torch.optim.lr_scheduler", "types.CodeType"),
+                      ("torch", "optim.lr_scheduler.types.FunctionType"), ("collections", "OrderedDict.fromkeys"),
+                      ("builtins", "dict.fromkeys"), ("os", "system"), ("builtins", "eval"), ("builtins", "getattr")):
+        with pytest.raises(pickle.UnpicklingError):
+            u.find_class(mod, name)
+    assert u.find_class("torch.optim.lr_scheduler", "partial") is _Inert
+    assert u.find_class("torch.optim.lr_scheduler", "CosineAnnealingLR") is _Inert
+    assert u.find_class("torch.optim.sgd", "SGD") is _Inert
+    # end to end, protocol 4 (STACK_GLOBAL, the dotted-name path of the C unpickler), inside a real torch zip:
+    # partial(os.system, "touch marker")() -- with the old rule `partial` resolved to functools.partial
+    def sglobal(m, n):
+        return (b"\x8c" + bytes([len(m)]) + m.encode() + b"\x8c" + bytes([len(n)]) + n.encode() + b"\x93")
+    cmd = f"touch {marker}".encode()
+    evil = (b"\x80\x04" + sglobal("torch.optim.lr_scheduler", "partial") + sglobal("os", "system")
+            + b"\x8c" + bytes([len(cmd)]) + cmd + b"\x86R" + b")R.")           # partial(os.system, cmd)()
+    f = str(tmp_path / "evil4.pth")
+    _torch_zip_with_pickle(f, evil)
+    with pytest.raises(pickle.UnpicklingError, match="not allowed"):
+        load_checkpoint_file(f)
+    assert not marker.exists()
+    dotted = b"\x80\x04" + sglobal("torch.optim.lr_scheduler", "types.FunctionType") + b"."
+    f = str(tmp_path / "dotted.pth")
+    _torch_zip_with_pickle(f, dotted)
+    with pytest.raises(pickle.UnpicklingError, match="dotted"):
+        load_checkpoint_file(f)
+    # `partial` alone (no os.system in reach) is inert: calling it builds nothing callable
+    harmless = (b"\x80\x04" + sglobal("torch.optim.lr_scheduler", "partial") + b"K\x01\x85R.")
+    f = str(tmp_path / "partial.pth")
+    _torch_zip_with_pickle(f, harmless)
+    assert type(load_checkpoint_file(f)).__name__ == "_Inert"
 
 
 def test_gradsync_leaves_the_current_device_alone_outside_a_launcher(monkeypatch):
