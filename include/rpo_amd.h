@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 4
+#define RPO_ABI_VERSION 5
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -278,6 +278,57 @@ typedef struct rpo_attn_bwd_args {
   float scale;
 } rpo_attn_bwd_args;
 int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_attn_bwd_args* a1, int dtype, void* stream);
+
+/* ---- the prompt-row backward chain of one tower as ONE persistent launch (ABI 5) --------------------------------------
+ * Replaces, for all `layers` blocks, the six launches per block that autograd's backward through
+ * clip/model.py:181-191 (ResidualAttentionBlock) costs for the back-propagated rows of trainers/rpo.py:308:
+ *     d c_proj GEMM x QuickGELU'  ->  d c_fc GEMM  ->  LayerNorm (ln_2) backward + residual
+ *     ->  d out-proj GEMM  ->  attention backward (dq only: keys / values belong to frozen tokens)
+ *     ->  d q-proj GEMM  ->  LayerNorm (ln_1) backward + residual
+ * Every back-propagated row depends only on rows of its own unit (an image of the image tower, a class of the text
+ * tower), so the units are dealt to 8 groups of `wgs_per_group` workgroups (workgroup b belongs to group b % 8, which
+ * the hardware's round-robin places on XCD b % 8) and each group walks the 6 x layers stages on its own rows, exchanging
+ * tiles through its XCD's L2 and ONE counter per group instead of a kernel boundary per stage.  The kernel verifies
+ * with HW_REG_XCC_ID that a group's workgroups really share an XCD; if not (or RPO_CHAIN_SAFE=1) it adds the agent-scope
+ * release (L2 write-back) per hand-off that cross-XCD visibility needs -- results never depend on placement.
+ * 16-bit storage only; d = H * 64 in {512, 768}; Kp <= 32; keys <= 224; at most 96 rows per group
+ * (units = 8 * m or fewer than 8 ...: ceil(units / 8) * Kp <= 96); the saved QuickGELU operand must be the derivative
+ * in the act dtype (rpo_gemm_args.aux_dtype = in_dtype); anything else returns RPO_E_SHAPE and nothing is enqueued.
+ * On entry dxa / dxc hold dL/d(output of the last block) of the rows (fp32 / act dtype); on return dxa holds
+ * dL/d(input of block 0).  state: caller-owned device scratch of rpo_chain_state_bytes() bytes, zeroed by a memset node
+ * this call enqueues; after the launch state[0] != 0 means a bounded spin gave up (results undefined). */
+typedef struct rpo_chain_layer {
+  const void* w_proj_t;      /* [4d, d]: c_proj.weight^T  (the dX operand of c_proj)                      */
+  const void* w_fc_t;        /* [d, 4d]: c_fc.weight^T                                                     */
+  const void* w_out_t;       /* [d, d]:  out_proj.weight^T                                                 */
+  const void* w_q_t;         /* [d, d]:  in_proj_weight[:d]^T                                              */
+  const void* aux;           /* [rows, 4d] act dtype: d quickgelu / du saved by the forward                */
+  const float* x_ln2;        /* [rows, ldx] fp32: input of ln_2 in the forward (x + attn)                  */
+  const float* x_ln1;        /* [rows, ldx] fp32: input of ln_1 (the block's input)                        */
+  const float* ln2_w; const float* ln1_w;   /* LayerNorm gains, fp32 [d]                                   */
+  const void* q_rows;        /* q of the back-propagated rows, act dtype, leading dimension ldq            */
+  const void* k; const void* v;   /* keys / values of the frozen tokens, leading dimension ldkv            */
+} rpo_chain_layer;
+typedef struct rpo_chain_bwd_args {
+  const rpo_chain_layer* layer;   /* HOST array [layers], block 0 first (the chain walks it backwards)      */
+  int32_t layers, units, Kp, d, H, keys, dtype;
+  const int32_t* key_len; int32_t key_stride;   /* as rpo_attn_bwd_args (NULL: every unit has `keys` keys)  */
+  int64_t ldx, ldq, ldkv;
+  float* dxa; float* dxb;    /* fp32 [units * Kp, d]                                                        */
+  void* dxc;                 /* act dtype [units * Kp, d]                                                   */
+  void* du;                  /* act dtype [units * Kp, 4d]                                                  */
+  void* dq;                  /* act dtype [units * Kp, d]                                                   */
+  float* dy; int64_t dy_stride;   /* fp32, 4 slabs of [units * Kp, d], dy_stride elements apart             */
+  float scale, eps;
+  int32_t wgs_per_group;     /* 0 = 32 (one workgroup per CU and chain on a 256-CU part); 32 .. 64               */
+  void* state;               /* device scratch, rpo_chain_state_bytes() bytes                               */
+  uint64_t* timeline;        /* optional device buffer of >= 1 + 7 * layers entries: s_memrealtime (100 MHz) of
+                                workgroup 0 at every stage boundary; NULL = off                            */
+} rpo_chain_bwd_args;
+size_t rpo_chain_state_bytes(void);
+int rpo_chain_bwd(const rpo_chain_bwd_args* args, void* stream);
+/* 1 if rpo_chain_bwd covers these sizes (only layers, units, Kp, d, H, keys, dtype are looked at), else 0 */
+int rpo_chain_bwd_ok(const rpo_chain_bwd_args* args);
 
 /* Text-tower attention for `rows` query rows per class against that class's cached keys /
  * values kc, vc [n_cls * Lmax, ldkv] (class c uses rows c*Lmax .. c*Lmax + len[c]).

@@ -73,6 +73,28 @@ class AttnBwdArgs(C.Structure):
                 ("key_len", c_vp), ("key_stride", c_i32), ("scale", c_f32)]
 
 
+class ChainLayer(C.Structure):
+    """struct rpo_chain_layer (include/rpo_amd.h)."""
+    _fields_ = [("w_proj_t", c_vp), ("w_fc_t", c_vp), ("w_out_t", c_vp), ("w_q_t", c_vp), ("aux", c_vp),
+                ("x_ln2", c_vp), ("x_ln1", c_vp), ("ln2_w", c_vp), ("ln1_w", c_vp),
+                ("q_rows", c_vp), ("k", c_vp), ("v", c_vp)]
+
+
+class ChainBwdArgs(C.Structure):
+    """struct rpo_chain_bwd_args (include/rpo_amd.h)."""
+    _fields_ = [("layer", C.POINTER(ChainLayer)),
+                ("layers", c_i32), ("units", c_i32), ("Kp", c_i32), ("d", c_i32), ("H", c_i32), ("keys", c_i32),
+                ("dtype", c_i32),
+                ("key_len", c_vp), ("key_stride", c_i32),
+                ("ldx", c_i64), ("ldq", c_i64), ("ldkv", c_i64),
+                ("dxa", c_vp), ("dxb", c_vp), ("dxc", c_vp), ("du", c_vp), ("dq", c_vp),
+                ("dy", c_vp), ("dy_stride", c_i64),
+                ("scale", c_f32), ("eps", c_f32),
+                ("wgs_per_group", c_i32),
+                ("state", c_vp),
+                ("timeline", c_vp)]
+
+
 # name -> (restype, argtypes); must list every symbol include/rpo_amd.h declares
 SIGNATURES = {
     "rpo_version": (c_i32, []),
@@ -83,6 +105,9 @@ SIGNATURES = {
     "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
     "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),
     "rpo_attn_bwd_proj_pair": (c_i32, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_i32, c_vp]),
+    "rpo_chain_state_bytes": (C.c_size_t, []),
+    "rpo_chain_bwd": (c_i32, [C.POINTER(ChainBwdArgs), c_vp]),
+    "rpo_chain_bwd_ok": (c_i32, [C.POINTER(ChainBwdArgs)]),
     "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                   c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i64, c_vp]),

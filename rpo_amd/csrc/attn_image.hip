@@ -455,7 +455,7 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
                                               int64_t ldkv, const T* da, int64_t ldda,
                                               T* dq, int64_t lddq, int B, int H, int N, int Kp,
                                               float scale, const T* wo, int64_t ldwo,
-                                              const int32_t* key_len, int key_stride) {
+                                              const int32_t* key_len, int key_stride, const bool plain_order = false) {
   using L = AL<T, NT>;
   constexpr int stat_off = NCW > 0 && L::BWD_BYTES < 65536 ? 65536 : L::BWD_BYTES;   // launchers allocate stat_off + 2048
   const int tid = threadIdx.x, lane = tid & 63;
@@ -466,7 +466,8 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
 #ifdef RPO_ATTN_PLAIN_ORDER
   const int wgid = bid;
 #else
-  const int wgid = [&] {
+  // (plain_order: bid IS the (group, head) index -- the persistent chain kernel, chain.hip, places its items itself)
+  const int wgid = plain_order ? bid : [&] {
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }();
@@ -897,6 +898,7 @@ int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void
 
 }  // namespace
 
+#ifndef RPO_DEVICE_ONLY     // (chain.hip includes this file for the device bodies above)
 extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld, void* out,
                                           int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
                                           int q_first, void* stream);
@@ -981,3 +983,4 @@ extern "C" int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_att
   if (dtype == RPO_BF16) return dispatch_bwd_proj_args<bf16_t>(a0, a1, s);
   return dispatch_bwd_proj_args<f16_t>(a0, a1, s);
 }
+#endif  // RPO_DEVICE_ONLY

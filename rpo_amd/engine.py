@@ -197,6 +197,12 @@ class Engine:
         self.d_img_f = f32(Rp, e)
         self.d_img_f_a = a(Rp, e)
         self.dy_v = f32(max(SPLIT_FC, SPLIT_Q), Rp, dv)
+        # the persistent backward chain (rpo_chain_bwd): 4 k-slice slabs, its scratch (one per tower: the two chains run
+        # concurrently), optional stage timeline (tools/chain_timeline.py sets it)
+        self.dy4_v = f32(4, Rp, dv)
+        self.chain_state_v = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev)
+        self.chain_state_t = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev)
+        self.chain_timeline = None
         self.dxa_v, self.dxb_v = f32(Rp, dv), f32(Rp, dv)
         self.dxc_v = a(Rp, dv)
         self.du_v = a(Rp, 4 * dv)
@@ -217,6 +223,7 @@ class Engine:
         self.d_text_f_a = a(Rt, e)
         self.ln_stats_t = f32(Rt, dt // 64, 2)
         self.dy_t = f32(max(SPLIT_FC, SPLIT_Q), Rt, dt)
+        self.dy4_t = f32(4, Rt, dt)
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
         self.du_t = a(Rt, 4 * dt)
@@ -520,11 +527,38 @@ class Engine:
                 ops.attn_readonly_bwd(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da, dq,
                                       nb, H, N, K, SCALE)
 
-        dx = self._rows_backward(self.vis, [t[Rf + r0:Rf + r1] for t in self.x[:-1]], [t[Rf + r0:Rf + r1] for t in self.xm],
-                                 [t[r0:r1] for t in self.u], dxa, dxb, dxc, self.du_v[r0:r1], self.da_v[r0:r1],
-                                 self.dq_v[r0:r1], self.dy_v[:, r0:r1], attn_bwd, fold_out=fold_out)
+        if self.chain_ok("v", nb):
+            # the 6 x layers stages as ONE persistent launch (rpo_chain_bwd, csrc/chain.hip): A/B switch RPO_CHAIN=0
+            layers = [dict(w_proj_t=b.w_proj_t, w_fc_t=b.w_fc_t, w_out_t=b.w_out_t, w_q_t=b.w_q_t, aux=self.u[l][r0:r1],
+                           x_ln2=self.xm[l][Rf + r0:Rf + r1], x_ln1=self.x[l][Rf + r0:Rf + r1], ln2_w=b.ln2_w, ln1_w=b.ln1_w,
+                           q_rows=self.qkv[l][Rf + r0:Rf + r1, :dv], k=self.qkv[l][f0:f1, dv:2 * dv],
+                           v=self.qkv[l][f0:f1, 2 * dv:]) for l, b in enumerate(self.vis)]
+            ops.chain_bwd(layers, units=nb, Kp=K, d=dv, H=H, keys=N, dtype=self.act, ldx=dv, ldq=3 * dv, ldkv=3 * dv,
+                          dxa=dxa, dxb=dxb, dxc=dxc, du=self.du_v[r0:r1], dq=self.dq_v[r0:r1], dy=self.dy4_v[:, r0:r1],
+                          scale=SCALE, state=self.chain_state_v, timeline=self.chain_timeline)
+            dx = dxa
+        else:
+            dx = self._rows_backward(self.vis, [t[Rf + r0:Rf + r1] for t in self.x[:-1]], [t[Rf + r0:Rf + r1] for t in self.xm],
+                                     [t[r0:r1] for t in self.u], dxa, dxb, dxc, self.du_v[r0:r1], self.da_v[r0:r1],
+                                     self.dq_v[r0:r1], self.dy_v[:, r0:r1], attn_bwd, fold_out=fold_out)
         # through ln_pre (rpo.py:206) to the appended prompt rows
         ops.layernorm_bwd(dx, self.x_pre[Rf + r0:Rf + r1], self.ln_pre[0], None, dxb)
+
+    def chain_ok(self, tower: str, units: int) -> bool:
+        """Whether the prompt-row backward chain of a tower ("v" / "t") runs as one persistent launch (rpo_chain_bwd):
+        16-bit modes with the QuickGELU derivative saved in the act dtype, widths / key counts / rows per group the
+        kernel covers.  OPT-IN (RPO_CHAIN=1; the text tower also needs RPO_CHAIN_TEXT=1): measured SLOWER than the
+        launch-per-stage chain -- image tower at B = 32: 1.10-1.20 ms against 0.77 ms (profiles/r04_chain_*.txt).  A
+        stage costs ~5-6 us of drain + counter + poll + first dependent load whether or not a kernel boundary sits in
+        it, and one workgroup per CU cannot keep enough LDS-DMA bytes in flight (72 KB ring: ~40 GB/s per CU)."""
+        if self.act == torch.float32 or os.environ.get("RPO_CHAIN") != "1" or os.environ.get("RPO_AUX_F32") == "1":
+            return False
+        cfg = self.cfg
+        if tower == "v":
+            return ops.chain_bwd_ok(cfg.layers_v, units, cfg.K, cfg.d_v, cfg.heads_v, cfg.n_frozen, self.act)
+        if os.environ.get("RPO_CHAIN_TEXT", "0") != "1" or self.Lmax > 96:
+            return False
+        return ops.chain_bwd_ok(cfg.layers_t, units, cfg.K, cfg.d_t, cfg.heads_t, self.Lmax, self.act)
 
     def _image_backward_finish(self, B: int) -> None:
         """sum over the batch (.repeat, rpo.py:204)"""
@@ -641,8 +675,18 @@ class Engine:
             else:
                 ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
 
-        dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
-                                 self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out)
+        if self.chain_ok("t", n):
+            # opt-in (RPO_CHAIN=1 RPO_CHAIN_TEXT=1): the text tower's chain as one persistent launch, classes as units
+            layers = [dict(w_proj_t=b.w_proj_t, w_fc_t=b.w_fc_t, w_out_t=b.w_out_t, w_q_t=b.w_q_t, aux=self.ut[l],
+                           x_ln2=self.xtm[l], x_ln1=self.xt[l], ln2_w=b.ln2_w, ln1_w=b.ln1_w, q_rows=self.qt[l],
+                           k=self.kv_t[l][:, :dt], v=self.kv_t[l][:, dt:]) for l, b in enumerate(self.txt)]
+            ops.chain_bwd(layers, units=n, Kp=K, d=dt, H=H, keys=self.Lmax, dtype=self.act, key_len=self.len_i32,
+                          key_stride=self.Lmax, ldx=dt, ldq=dt, ldkv=2 * dt, dxa=dxa, dxb=dxb, dxc=dxc, du=self.du_t,
+                          dq=self.dq_t, dy=self.dy4_t, scale=SCALE, state=self.chain_state_t)
+            dx = dxa
+        else:
+            dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
+                                     self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out)
         ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
 
     # ------------------------------------------------------------------ public

@@ -275,6 +275,42 @@ def attn_readonly_bwd(q_rows, k, v, da, dq, B: int, H: int, N: int, Kp: int, sca
     return dq
 
 
+def chain_state() -> int:
+    """bytes of device scratch rpo_chain_bwd needs (counters, placement table)"""
+    return int(_lib.load().rpo_chain_state_bytes())
+
+
+def _chain_args(layers: list, units: int, Kp: int, d: int, H: int, keys: int, dtype: torch.dtype, key_len=None,
+                key_stride: int = 0, ldx: int = 0, ldq: int = 0, ldkv: int = 0, dxa=None, dxb=None, dxc=None, du=None,
+                dq=None, dy=None, scale: float = 0.125, eps: float = 1e-5, wgs_per_group: int = 0, state=None,
+                timeline=None):
+    arr = (_lib.ChainLayer * max(1, len(layers)))()
+    for i, L in enumerate(layers):
+        arr[i] = _lib.ChainLayer(*[_p(L[k]) for k in ("w_proj_t", "w_fc_t", "w_out_t", "w_q_t", "aux", "x_ln2", "x_ln1",
+                                                       "ln2_w", "ln1_w", "q_rows", "k", "v")])
+    a = _lib.ChainBwdArgs(layer=arr, layers=len(layers), units=units, Kp=Kp, d=d, H=H, keys=keys, dtype=dtype_code(dtype),
+                          key_len=_p(key_len), key_stride=key_stride, ldx=ldx, ldq=ldq, ldkv=ldkv, dxa=_p(dxa), dxb=_p(dxb),
+                          dxc=_p(dxc), du=_p(du), dq=_p(dq), dy=_p(dy), dy_stride=(dy.stride(0) if dy is not None else 0),
+                          scale=scale, eps=eps, wgs_per_group=wgs_per_group, state=_p(state), timeline=_p(timeline))
+    a._keep = arr
+    return a
+
+
+def chain_bwd_ok(layers: int, units: int, Kp: int, d: int, H: int, keys: int, dtype: torch.dtype) -> bool:
+    if dtype == torch.float32:
+        return False
+    a = _lib.ChainBwdArgs(layers=layers, units=units, Kp=Kp, d=d, H=H, keys=keys, dtype=dtype_code(dtype))
+    return bool(_lib.load().rpo_chain_bwd_ok(C.byref(a)))
+
+
+def chain_bwd(layers: list, **kw) -> None:
+    """The prompt-row backward chain of one tower as one persistent launch (include/rpo_amd.h: rpo_chain_bwd).
+    layers: one dict per block (block 0 first) with the tensors of struct rpo_chain_layer; x_ln2 / x_ln1 / q_rows are
+    views of the back-propagated rows; dy: fp32 [4, rows, d] slabs."""
+    a = _chain_args(layers, **kw)
+    check(_lib.load().rpo_chain_bwd(C.byref(a), _stream()), "rpo_chain_bwd")
+
+
 def text_attn_fwd(q, kc, vc, out, len_i32, n_cls: int, rows: int, Lmax: int, H: int, causal: bool = False,
                   scale: float = 0.125):
     assert _ld(kc) == _ld(vc) and len_i32.dtype == torch.int32

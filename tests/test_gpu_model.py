@@ -949,6 +949,50 @@ def test_joint_backward_equals_the_two_chains(monkeypatch, B):
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("case", ["d2_k8_b3", "full_b32", "full_b16_f16"])
+def test_persistent_backward_chain_matches_the_launch_chain(monkeypatch, case):
+    """rpo_chain_bwd (csrc/chain.hip, opt-in RPO_CHAIN=1): the 7 x layers stages of a tower's prompt-row backward as ONE
+    persistent launch, 8 XCD-local groups handing tiles over through one counter each.  Same inputs, both towers:
+    gradients within the 16-bit modes' rounding of the launch-per-stage chain (different k-slicing of the fp32 sums,
+    16-bit intermediates rounded at the same points); no bounded spin gave up; the placement-independent protocol
+    (RPO_CHAIN_SAFE=1: agent-scope release per hand-off) gives the SAME BITS as the XCD-local one the kernel picks after
+    checking HW_REG_XCC_ID; uneven unit counts (3 images, 19 classes over 8 groups) leave no row behind."""
+    from rpo_amd.custom_clip import CustomCLIP
+    if case == "d2_k8_b3":
+        cfg, sd, toks, tp, ip, image, label = workload(case)
+        act, tol = torch.bfloat16, 2e-2
+    else:
+        cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 24, 32)
+        act, tol = (torch.float16, 2e-3) if case.endswith("f16") else (torch.bfloat16, 2e-2)
+        if "b16" in case:
+            image, label = image[:16], label[:16]
+    B = image.shape[0]
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=B, prompts=(tp, ip))
+    eng = m.engine
+    monkeypatch.delenv("RPO_CHAIN", raising=False)
+    eng.forward_backward(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    torch.cuda.synchronize()
+    ref_i, ref_t = eng.g_img.clone(), eng.g_text.clone()
+    monkeypatch.setenv("RPO_CHAIN", "1")
+    monkeypatch.setenv("RPO_CHAIN_TEXT", "1")
+    assert eng.chain_ok("v", B) and eng.chain_ok("t", cfg.n_cls)
+    eng.g_img.zero_(); eng.g_text.zero_()
+    eng._image_backward(B); eng._text_backward()
+    torch.cuda.synchronize()
+    got_i, got_t = eng.g_img.clone(), eng.g_text.clone()
+    for st in (eng.chain_state_v, eng.chain_state_t):
+        assert int(st[0]) == 0, "a bounded spin of the persistent chain gave up"
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(got_i, ref_i) < tol and rel(got_t, ref_t) < tol, (rel(got_i, ref_i), rel(got_t, ref_t))
+    fast_groups = 8 - int(eng.chain_state_v[1])
+    monkeypatch.setenv("RPO_CHAIN_SAFE", "1")
+    eng._image_backward(B); eng._text_backward()
+    torch.cuda.synchronize()
+    assert int(eng.chain_state_v[1]) == min(8, B) and int(eng.chain_state_v[0]) == 0
+    assert torch.equal(eng.g_img, got_i) and torch.equal(eng.g_text, got_t), "results depend on the hand-off protocol"
+    assert fast_groups >= 0
+
+
 # The residual stream as the 16-bit hi half alone (RPO_RESID16=1, opt-in; in fp16 what the reference's own `PREC: fp16`
 # run does, clip/model.py:379-400,153-159): its own tolerance rows against the reference's fp32 CPU outputs -- max abs
 # error on logits and loss, max relative error (to the largest entry) on the prompt gradients.  (fp16: 7.6e-3 measured
