@@ -366,6 +366,91 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def bench_sibling(args):
+    """One JSON line for the CoOp / CoCoOp train step (the same contract as the RPO line: K timed steps
+    between synchronisations, inputs resident in HBM, synthetic data).  The step is replayed from one HIP graph."""
+    from rpo_amd.config import flops_coop_step
+    from rpo_amd.coop import CoCoOp, CoOp
+    from rpo_amd.trainer import OptimConfig
+    coop = args.trainer == "coop"
+    n_ctx = args.n_ctx or (16 if coop else 4)
+    batch = args.batch if args.batch_given else (32 if coop else 1)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    cfg = (vit_b16 if args.model == "ViT-B/16" else vit_l14)(K=1)          # (one unused RPO prompt row per image)
+    base = synth.default_tokens(cfg)
+    toks = synth.coop_tokens(base, n_ctx)
+    lens = synth.len_prompts(toks)
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    act = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    torch.manual_seed(0)
+    oc = OptimConfig(lr=0.002, warmup_epoch=0, lr_scheduler="constant")
+    Tr = CoOp if coop else CoCoOp
+    tr = Tr(sd, toks, n_ctx, oc, dev, act, batch_size=batch, num_batches=10 ** 9, use_graph=not args.no_graph)
+    pool = 4
+    imgs = [torch.from_numpy(synth.images(cfg, batch, seed=1234 + 17 * i)).to(dev) for i in range(pool)]
+    labs = [torch.from_numpy(synth.labels(cfg, batch, seed=4321 + 17 * i)).to(dev) for i in range(pool)]
+    for i in range(max(args.warmup, 2)):                 # (step 0 is eager, step 1 captures the graph)
+        tr.step_async(imgs[i % pool], labs[i % pool])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step_async(imgs[i % pool], labs[i % pool])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / args.steps
+    fl = flops_coop_step(cfg, batch, lens, replicas=1 if coop else batch)
+    peak = PEAK_TFLOPS[args.dtype]
+    name = "CoOp" if coop else "CoCoOp"
+    out = {"metric": f"images/sec (train step, {name} {args.model} n_ctx={n_ctx})", "value": round(batch * args.steps / dt, 2),
+           "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"{name} ({'trainers/coop.py:258-281' if coop else 'trainers/cocoop.py:255-275'}), {cfg.name}, "
+                                  f"n_ctx={n_ctx}, class token at the end, generic context, synthetic {cfg.image_size}x"
+                                  f"{cfg.image_size}, batch={batch}, n_cls={cfg.n_cls}: plain image tower forward + dense text "
+                                  f"tower forward / backward ({'once' if coop else 'once per image'}) + head + SGD",
+                      "global_batch": batch, "parallelism": "dp1", "hip_graph": not args.no_graph,
+                      "final_loss": round(float(loss.item()), 5)},
+           "roofline": {"bound": "mfma", "achieved": round(fl / (dt / args.steps) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(fl / (dt / args.steps) / 1e12 / peak, 4), "traffic": None,
+                        "algorithmic_gflop_per_step": round(fl / 1e9, 2),
+                        "note": "algorithmic FLOPs: rpo_amd.config.flops_coop_step (image tower forward for every image, dense "
+                                "text tower forward + dX backward over the tokens up to each class's EOT)"}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_sibling(cfg, toks, n_ctx, batch, coop)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_sibling(cfg, toks, n_ctx, batch, coop, budget_s: float = 25.0):
+    """The oracle's CoOp / CoCoOp step (reference-equivalent dense fp32 autograd; pinned to the reference's own trainers by
+    tests/test_oracle_golden.py) on the host cores, bounded sample."""
+    from oracle.rpo_oracle import cocoop_loss_and_grads, coop_loss_and_grad
+    nthr = usable_cores()
+    torch.set_num_threads(nthr)
+    full = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    g = torch.Generator().manual_seed(0)
+    ctx = (torch.randn(n_ctx, cfg.d_t, generator=g) * 0.02).numpy()
+    h = cfg.embed // 16
+    meta = dict(w1=(torch.randn(h, cfg.embed, generator=g) * 0.02).numpy(), b1=np.zeros(h, np.float32),
+                w2=(torch.randn(cfg.d_t, h, generator=g) * 0.02).numpy(), b2=np.zeros(cfg.d_t, np.float32))
+    times, t0 = [], time.perf_counter()
+    for i in range(6):
+        im, lb = synth.images(cfg, batch, seed=900 + i), synth.labels(cfg, batch, seed=950 + i)
+        t1 = time.perf_counter()
+        if coop:
+            coop_loss_and_grad(full, im, toks, ctx, lb, cfg.patch)
+        else:
+            cocoop_loss_and_grads(full, im, toks, ctx, meta, lb, cfg.patch)
+        if i > 0:
+            times.append(time.perf_counter() - t1)       # (the first call is the warm-up)
+        if time.perf_counter() - t0 > budget_s and times:
+            break
+    return {"value": round(batch * len(times) / sum(times), 3), "unit": "images/sec", "cores": nthr, "kind": "port",
+            "cpu_model": cpu_model(), "ms_per_step": round(1e3 * sum(times) / len(times), 1),
+            "sample": f"oracle {'coop_loss_and_grad' if coop else 'cocoop_loss_and_grads'} (dense fp32 forward + autograd), "
+                      f"batch {batch}: 1 warm-up + {len(times)} timed steps, {nthr} threads"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,12 +462,22 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trainer", choices=["rpo", "coop", "cocoop"], default="rpo",
+                    help="rpo (default): the north-star step.  coop / cocoop: the sibling trainers of SURVEY 8f on the same "
+                         "engine (trainers/coop.py:258-281, trainers/cocoop.py:255-275) at the reference's defaults "
+                         "(CoOp: batch 32, n_ctx 16; CoCoOp: batch 1, n_ctx 4) unless --batch / --n-ctx say otherwise")
+    ap.add_argument("--n-ctx", type=int, default=0, help="context vectors of --trainer coop / cocoop (0: the default)")
     ap.add_argument("--no-precision", action="store_true", help="skip the bf16-vs-f32 error report")
     ap.add_argument("--input-pipeline", action="store_true", help="also time the on-device input transforms")
     ap.add_argument("--eval-batch", type=int, default=0,
                     help="also time the eval branch (logits only, text features cached) at this batch size")
     args = ap.parse_args()
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
 
+    if args.trainer != "rpo":
+        if args.gpus != 1:
+            raise SystemExit("--trainer coop / cocoop is a single-GPU measurement")
+        return bench_sibling(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))         # re-exec under torch.distributed.run, one rank per GPU
     sync = GradSync()                                    # reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
@@ -390,6 +485,7 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={sync.world_size}: launch one rank per GPU")
     dev = torch.device(f"cuda:{sync.local_rank}")
     torch.cuda.set_device(dev)
+    host = sync.pin_host() if sync.world_size > 1 else {"pinned": False}     # cores of this GPU's NUMA node, capped threads
 
     from rpo_amd.trainer import RPO, OptimConfig
     cfg = (vit_b16 if args.model == "ViT-B/16" else vit_l14)(K=args.K)
@@ -435,6 +531,7 @@ def main() -> None:
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     dt = sync.max_over_ranks(dt_local, dev)
+    per_rank_ms = [1e3 * t / args.steps for t in sync.gather_floats(dt_local, dev)]
     last_loss = float(loss.item())
     coll_us = None
     if sync.enabled:
@@ -469,6 +566,14 @@ def main() -> None:
                    "collective": sync.describe(),
                    "collective_us": None if coll_us is None else round(coll_us, 1),
                    "collective_bytes": int(tr.engine.grads.numel() * 4) if sync.enabled else 0,
+                   # N > 1: the text half goes out behind the text backward (under the image backward), the image half
+                   # after it; share = what the two all-reduces would cost back to back, relative to the step
+                   "collective_schedule": ("split: g_text behind the text chain, g_img after the image chain"
+                                           if getattr(tr, "_split_collective", False) else "one all-reduce after the join"),
+                   "collective_share_of_step": None if coll_us is None else round(coll_us / (1e3 * ms), 4),
+                   "rank_ms_per_step": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
+                                        "all": [round(v, 4) for v in per_rank_ms]},
+                   "host": host,
                    "hip_graph": not args.no_graph, "final_loss": round(last_loss, 5)},
         "roofline": {"bound": "mfma",
                      # the stricter figure first: FLOPs the engine really EXECUTES per step (the SURVEY 8d contract

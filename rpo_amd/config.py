@@ -125,6 +125,21 @@ def flops_step(cfg: RPOConfig, batch: int, len_prompts) -> float:
     return batch * (f + b) + flops_text(cfg, len_prompts) + batch * 2.0 * cfg.K * cfg.embed * cfg.n_cls
 
 
+def flops_coop_step(cfg: RPOConfig, batch: int, lens, replicas: int = 1) -> float:
+    """Algorithmic FLOPs of one CoOp (replicas = 1) / CoCoOp (replicas = batch) train step, trainers/coop.py:258-281 /
+    trainers/cocoop.py:255-275: the plain image tower forward for `batch` images (all N tokens through all blocks; no
+    backward -- nothing trainable sits in front of it), and the DENSE text tower forward + backward-to-input for the
+    tokens [0, len_c) of every class (causal attention counted as the lower triangle; backward: the dX GEMMs of the four
+    linears -- weights frozen -- and 2x the attention's forward), once per replica; projections and head on top."""
+    Lv, dv, N, e = cfg.layers_v, cfg.d_v, cfg.n_frozen, cfg.embed
+    Lt, dt = cfg.layers_t, cfg.d_t
+    img = Lv * (24.0 * N * dv * dv + 4.0 * N * N * dv) + 2.0 * (N - 1) * dv * cfg.patch_dim + 2.0 * dv * e
+    T = float(sum(int(l) for l in lens))
+    tri = float(sum(int(l) * (int(l) + 1) // 2 for l in lens))
+    text = Lt * (48.0 * T * dt * dt + 3.0 * 4.0 * tri * dt) + 2.0 * 2.0 * len(lens) * dt * e
+    return batch * img + replicas * text + 4.0 * batch * len(lens) * e
+
+
 def flops_last_block_dead(cfg: RPOConfig) -> float:
     """FLOPs per image that flops_image (the SURVEY 8d contract figure) counts but the engine does not execute: in the
     LAST image block only the K prompt rows are consumed (ln_post, trainers/rpo.py:210), so the N frozen rows skip

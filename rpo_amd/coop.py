@@ -96,7 +96,7 @@ class CoOp:
     def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int = 16,
                  optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
                  act_dtype: torch.dtype = torch.float16, batch_size: int = 32, num_batches: int = 1,
-                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None):
+                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None, use_graph: bool = False):
         self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=50)       # configs/trainers/CoOp/vit_b16_ep50.yaml
         self.model = CoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, cfg)
         self.engine, self.cfg = self.model.engine, self.model.cfg
@@ -104,6 +104,38 @@ class CoOp:
         self.batch_size, self.num_batches = batch_size, num_batches
         self.epoch = self.batch_idx = self._steps = 0
         self.lr = lr_at_epoch(self.optim_cfg, 0)
+        self.use_graph = use_graph
+        self._graph = None                               # (HIP graph of one step, the learning rate it was captured with)
+
+    def _enqueue(self, image: torch.Tensor, label: torch.Tensor) -> None:
+        eng, oc = self.engine, self.optim_cfg
+        eng.coop_forward_backward(image, label)
+        ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
+                     first_step=(self._steps == 0))
+
+    def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """One optimisation step, nothing synchronised; returns the device loss scalar.  With use_graph the ~250 launches
+        of a step (plain image tower, dense text tower forward + backward, head, SGD) are replayed from ONE HIP graph,
+        captured after the first (eager) step and again whenever the learning rate changes (it is a kernel argument)."""
+        if not self.use_graph or self._steps == 0 or image.shape[0] != self.batch_size:
+            self._enqueue(image, label)
+        else:
+            if self._graph is None or self._graph[1] != self.lr:
+                self._img = torch.empty_like(image)
+                self._lab = torch.empty_like(label)
+                self._img.copy_(image); self._lab.copy_(label)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._enqueue(self._img, self._lab)
+                self._graph = (g, self.lr)
+                # (capture does not execute: the replay below is this step)
+            if image.data_ptr() != self._img.data_ptr():
+                self._img.copy_(image, non_blocking=True)
+            self._lab.copy_(label, non_blocking=True)
+            self._graph[0].replay()
+        self._steps += 1
+        return self.engine.loss
 
     def parse_batch_train(self, batch):
         img = batch["img"].to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
@@ -118,10 +150,8 @@ class CoOp:
         eng, oc = self.engine, self.optim_cfg
         with torch.cuda.device(self.device):
             image, label = self.parse_batch_train(batch)
-            logits = eng.coop_forward_backward(image, label)
-            ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
-                         first_step=(self._steps == 0))
-            self._steps += 1
+            self.step_async(image, label)
+            logits = eng.logits[:image.shape[0]]
             acc = float((logits.argmax(1) == label).float().mean().item()) * 100.0      # compute_accuracy()[0]
             summary = {"loss": float(eng.loss.item()), "acc": acc}
         if (self.batch_idx + 1) == self.num_batches:
@@ -194,7 +224,7 @@ class CoCoOp(CoOp):
                  optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
                  act_dtype: torch.dtype = torch.float16, batch_size: int = 1, num_batches: int = 1,
                  ctx: Optional[np.ndarray] = None, meta: Optional[Dict[str, np.ndarray]] = None,
-                 cfg: Optional[RPOConfig] = None):
+                 cfg: Optional[RPOConfig] = None, use_graph: bool = False):
         self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=10)    # configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1.yaml
         self.model = CoCoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, meta, cfg)
         self.engine, self.cfg = self.model.engine, self.model.cfg
@@ -202,15 +232,20 @@ class CoCoOp(CoOp):
         self.batch_size, self.num_batches = batch_size, num_batches
         self.epoch = self.batch_idx = self._steps = 0
         self.lr = lr_at_epoch(self.optim_cfg, 0)
+        self.use_graph = use_graph
+        self._graph = None
+
+    def _enqueue(self, image: torch.Tensor, label: torch.Tensor) -> None:
+        eng, oc = self.engine, self.optim_cfg
+        eng.cocoop_forward_backward(image, label)
+        ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
+                     first_step=(self._steps == 0))
 
     def forward_backward(self, batch) -> Dict[str, float]:
         eng, oc = self.engine, self.optim_cfg
         with torch.cuda.device(self.device):
             image, label = self.parse_batch_train(batch)
-            eng.cocoop_forward_backward(image, label)
-            ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
-                         first_step=(self._steps == 0))
-            self._steps += 1
+            self.step_async(image, label)
             summary = {"loss": float(eng.loss.item())}
         if (self.batch_idx + 1) == self.num_batches:
             self.epoch += 1

@@ -22,6 +22,15 @@ import torch
 import torch.distributed as dist
 
 
+def _gpu_numa_node(idx: int) -> int:
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        return int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+    except Exception:
+        return -1
+
+
 class GradSync:
     def __init__(self, backend: Optional[str] = None, init: bool = True):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,6 +61,52 @@ class GradSync:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    # ---- host side of an N-rank node: SURVEY 8e names host jitter as THE scaling risk (each rank replays five graphs and
+    # one collective every ~3 ms), so under a launcher every rank pins itself to the cores of its GPU's NUMA node and
+    # caps its host thread pools.  RPO_NO_AFFINITY=1 leaves the process alone.
+    def pin_host(self, device_index: Optional[int] = None) -> dict:
+        """Restrict this process to the CPUs next to its GPU (sysfs: the PCI device's numa_node -> that node's cpulist,
+        intersected with what the process may use); without that information, an even share of the allowed CPUs by
+        local rank.  Caps torch's intra-op threads at the share.  Returns what was done (for the bench line)."""
+        info = {"pinned": False}
+        if os.environ.get("RPO_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+            return info
+        allowed = sorted(os.sched_getaffinity(0))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world_size)))
+        idx = self.local_rank if device_index is None else device_index
+        cpus, how = None, None
+        try:
+            props = torch.cuda.get_device_properties(idx)
+            bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+            node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+            if node >= 0:
+                cl = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+                want = set()
+                for part in cl.split(","):
+                    a, _, b = part.partition("-")
+                    want.update(range(int(a), int(b or a) + 1))
+                # ranks whose GPUs share the node split its cores among themselves
+                peers = sorted(set(range(local_world)))
+                same = [r for r in peers if _gpu_numa_node(r) == node] or [self.local_rank]
+                mine = sorted(want & set(allowed))
+                if mine:
+                    k = same.index(self.local_rank) if self.local_rank in same else 0
+                    per = max(1, len(mine) // len(same))
+                    cpus, how = mine[k * per:(k + 1) * per] or mine, f"numa node {node}"
+        except Exception:
+            cpus = None
+        if not cpus and local_world > 1:
+            per = max(1, len(allowed) // local_world)
+            cpus, how = allowed[self.local_rank * per:(self.local_rank + 1) * per] or allowed, "even share of the allowed cpus"
+        if cpus:
+            try:
+                os.sched_setaffinity(0, cpus)
+                torch.set_num_threads(max(1, min(len(cpus), 8)))
+                info = {"pinned": True, "cpus": len(cpus), "first_cpu": cpus[0], "how": how}
+            except OSError:
+                pass
+        return info
 
     def _pg(self) -> None:
         if not dist.is_initialized():
@@ -106,6 +161,16 @@ class GradSync:
             dist.broadcast_object_list(box, src=src)
             return box[0]
         return obj
+
+    def gather_floats(self, value: float, device) -> list:
+        """`value` of every rank, on every rank (bench: per-rank step times)."""
+        if not self.enabled:
+            return [float(value)]
+        self._pg()
+        t = torch.zeros(self.world_size, dtype=torch.float64, device=device)
+        t[self.rank] = value
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
 
     def max_over_ranks(self, value: float, device) -> float:
         t = torch.tensor([value], dtype=torch.float64, device=device)

@@ -243,6 +243,7 @@ class Engine:
         self.img_prompt = self.params[nt:].view(K, dv)
         self.g_text = self.grads[:nt].view(K, dt)
         self.g_img = self.grads[nt:].view(K, dv)
+        self.g_text_flat, self.g_img_flat = self.grads[:nt], self.grads[nt:]    # the two halves as collectives see them
         self.side = torch.cuda.Stream(device=dev)
 
     def hbm_bytes(self) -> int:
@@ -914,8 +915,18 @@ class Engine:
         e, n = cfg.embed, cfg.n_cls
         train = label is not None
         self.c_shift[0].copy_(self.coop_ctx)
-        self._coop_text_forward(train)
-        B = self._plain_image_features(image)
+        # the two towers are independent until the head: the (small, latency-bound) dense text forward runs on the side
+        # stream under the image tower, as RPO's text chain does (RPO_COOP_SERIAL=1: one stream)
+        if os.environ.get("RPO_COOP_SERIAL") == "1":
+            self._coop_text_forward(train)
+            B = self._plain_image_features(image)
+        else:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._coop_text_forward(train)
+            B = self._plain_image_features(image)
+            main.wait_stream(self.side)
         extra = {} if (not train or self.act == torch.float32) else dict(d_text_f_act=self.c_d_text_f_a[:n])
         ops.head_fwd_bwd(self.img_cls_f[:B].view(B, 1, e), self.c_text_f[:n].view(n, 1, e), label, self.logit_scale_exp,
                          self.logits[:B], self.loss if train else None,

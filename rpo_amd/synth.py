@@ -27,7 +27,7 @@ import json
 import math
 import os
 import zlib
-from typing import Dict, Iterable, List, Sequence
+from typing import Optional, Dict, Iterable, List, Sequence
 
 import numpy as np
 
@@ -219,6 +219,22 @@ def synthetic_tokens(cfg: RPOConfig, lengths: Sequence[int], seed: int = 99) -> 
         out[c, 0] = SOT_TOKEN
         out[c, 1:n - 1] = g.integers(1000, 40000, size=(n - 2,))
         out[c, n - 1] = EOT_TOKEN
+    return out
+
+
+def coop_tokens(base_tokens: np.ndarray, n_ctx: int, placeholder: Optional[int] = None) -> np.ndarray:
+    """Token ids of CoOp's "X X .. X name." prompts (trainers/coop.py:95-98: prompt_prefix + " " + name + ".") built from a
+    table of "SOS words EOT" rows: SOS, n_ctx placeholder ids, then the row's own words and its EOT.  The tokenizer is out
+    of scope; benchmarks and tests only need rows of that SHAPE whose ids have embedding rows."""
+    base = np.asarray(base_tokens, dtype=np.int64)
+    out = np.zeros_like(base)
+    ph = int(base[0, 1]) if placeholder is None else int(placeholder)
+    for c in range(base.shape[0]):
+        n = int(base[c].argmax()) + 1                     # SOS .. EOT
+        assert n + n_ctx <= base.shape[1]
+        out[c, 0] = base[c, 0]
+        out[c, 1:1 + n_ctx] = ph
+        out[c, 1 + n_ctx:n_ctx + n] = base[c, 1:n]
     return out
 
 

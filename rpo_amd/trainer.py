@@ -79,6 +79,8 @@ class RPO:
         self.batch_idx = 0
         self._steps = 0
         self._graph = None
+        self._joint_bwd = False
+        self._split_collective = False
         self.best_result = -float("inf")
         self._found_inf = None                       # amp: int32[2] on the device (this step's flag, skipped steps)
         # trainers/rpo.py:287-288 turns on autograd anomaly detection ("nan detector"); there is no autograd graph
@@ -150,6 +152,7 @@ class RPO:
         # both backward chains as one chain of paired launches where the kernels allow it (Engine._joint_backward)
         self._joint_bwd = eng.joint_backward_ok(B)
         self._bwd_parts = 1
+        self._split_collective = self.sync.enabled and os.environ.get("RPO_ONE_COLLECTIVE") != "1"
         if self._joint_bwd:
             self._g_bwd = cap(lambda: eng._joint_backward(B))
         else:
@@ -191,6 +194,11 @@ class RPO:
         side.wait_event(self._ev_head)
         with torch.cuda.stream(side):
             self._g_text_bwd.replay()
+            # N > 1: the text tower's gradient is complete here, ~0.15-0.3 ms before the image tower's: its all-reduce
+            # goes out now, behind the text chain on the side stream, and travels under the image backward
+            # (RPO_ONE_COLLECTIVE=1: one all-reduce of the whole buffer after the join, as before)
+            if self._split_collective:
+                self.sync.all_reduce_sum(self.engine.g_text_flat)
             self._ev_text_bwd.record(side)
         if self._bwd_parts > 1:
             for st, ev, g in zip(self._part_streams, self._ev_parts, self._g_img_bwd_parts[1:]):
@@ -236,7 +244,10 @@ class RPO:
             self._replay()
         else:
             eng.forward_backward(self._image, self._label)
-        self.sync.all_reduce_sum(eng.grads)
+        if self.use_graph and self._split_collective and not self._joint_bwd:
+            self.sync.all_reduce_sum(eng.g_img_flat)            # (g_text went out behind the text backward, _replay)
+        else:
+            self.sync.all_reduce_sum(eng.grads)
         if self.amp:
             if self._found_inf is None:
                 self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device)

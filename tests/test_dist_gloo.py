@@ -52,6 +52,17 @@ def _worker(rank, world, port, out_dir):
     grads *= sync.grad_scale
     mx = sync.max_over_ranks(float(rank), torch.device("cpu"))
     assert mx == world - 1
+    assert sync.gather_floats(10.0 + rank, torch.device("cpu")) == [10.0 + r for r in range(world)]
+    assert sync.broadcast_object({"dir": "x"} if rank == 0 else None) == {"dir": "x"}
+    # host pinning: without a GPU the even-share rule applies -- disjoint CPU sets per local rank, threads capped
+    before = sorted(os.sched_getaffinity(0))
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    info = sync.pin_host()
+    if len(before) >= world:
+        mine = sorted(os.sched_getaffinity(0))
+        assert info["pinned"] and len(mine) == len(before) // world and mine[0] == before[rank * (len(before) // world)]
+        assert torch.get_num_threads() <= len(mine)
+    os.sched_setaffinity(0, before)
     sync.barrier()
     np.save(os.path.join(out_dir, f"g{rank}.npy"), grads.numpy())
     sync.close()
@@ -74,6 +85,13 @@ def test_two_rank_gradient_equals_global_batch(tmp_path):
     _, gt, gi = m.loss_and_grads(synth.images(cfg, 4), synth.labels(cfg, 4))
     ref = np.concatenate([gt.numpy().reshape(-1), gi.numpy().reshape(-1)])
     assert np.abs(g0 - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_pin_host_can_be_switched_off(monkeypatch):
+    from rpo_amd.dist import GradSync
+    monkeypatch.setenv("RPO_NO_AFFINITY", "1")
+    before = os.sched_getaffinity(0)
+    assert GradSync(init=False).pin_host() == {"pinned": False} and os.sched_getaffinity(0) == before
 
 
 def test_shard_rejects_uneven_batches(monkeypatch):

@@ -342,7 +342,13 @@ def test_bench_eight_rank_flow_on_one_gpu():
     assert "8 ranks" in d["config"]["collective"]
     assert d["config"]["collective_us"] > 0 and d["config"]["collective_bytes"] == 4 * 24 * (512 + 768)
     assert "cpu_baseline" not in d and "precision" not in d      # N = 1 only
-    assert not glob.glob(os.path.join(tempfile.gettempdir(), f"rpo_amd_weights_{os.getuid()}_*")), "shared weight file left behind"
+    # round 4: the text half of the gradient goes out behind the text chain, the image half after the image chain; the
+    # line carries every rank's own step time and what the host pinning did
+    assert d["config"]["collective_schedule"].startswith("split") and 0 < d["config"]["collective_share_of_step"] < 1
+    rk = d["config"]["rank_ms_per_step"]
+    assert len(rk["all"]) == 8 and rk["min"] <= rk["max"] and abs(rk["max"] - d["ms_per_step"]) < 1e-3
+    assert "pinned" in d["config"]["host"]
+    assert not glob.glob(os.path.join(tempfile.gettempdir(), "rpo_amd_weights_*")), "shared weight directory left behind"
 
 
 @pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1), (4, 300, 2)])
