@@ -338,6 +338,41 @@ def committed_step_traffic(args):
     return None, None
 
 
+def committed_qkv_gemm(args):
+    """The north-star kernel figure (BASELINE.json: >= 70 % MFMA utilisation on the masked-attention QKV GEMM) from the
+    committed PMC summary of the same profile refresh as the traffic figure (profiles/rNN_gemm_pmc.txt; bench.py cannot
+    collect counters), under the same guard: attached only while rpo_amd/csrc hashes to what that refresh recorded."""
+    if (args.model, args.K, args.batch, args.dtype) != ("ViT-B/16", 24, 32, "bf16"):
+        return None
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_gemm_pmc.txt")))
+    if not files:
+        return None
+    tag = os.path.basename(files[-1]).split("_")[0]
+    sha = None
+    try:
+        for line in open(os.path.join(here, "profiles", f"{tag}_step_hbm_traffic.txt")):
+            if line.startswith("kernel_sources_sha1"):
+                sha = line.split()[1]
+    except OSError:
+        pass
+    res = {"target": 0.70, "source": os.path.relpath(files[-1], here)}
+    if sha is None or sha != kernel_sources_sha1():
+        res["stale"] = "kernel sources changed since the counters were collected: figures not attached"
+        return res
+    sect = False
+    for line in open(files[-1]):
+        if line.startswith("## "):
+            sect = line.startswith("## in-proj")
+        elif sect and line.startswith("-> MFMA pipe utilisation"):
+            res["mfma_busy_wall"] = float(line.split()[-1])
+        elif sect and line.startswith("-> MFMA busy / wave lifetime"):
+            res["mfma_busy_lifetime"] = float(line.split()[-1])
+    res["met"] = res.get("mfma_busy_lifetime", 0.0) >= 0.70
+    return res
+
+
 def kernel_sources_sha1() -> str:
     """Fingerprint of rpo_amd/csrc (what tools/summarize_profiles.py records next to a counter summary)."""
     import hashlib
@@ -587,7 +622,8 @@ def main() -> None:
                      "traffic_source": traffic_src,
                      "algorithmic_gflop_per_step_per_gpu": round(fl_step / 1e9, 2),
                      "gflop_per_image": round(sum(flops_image(cfg)) / 1e9, 2),
-                     "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2)},
+                     "gflop_text_per_step": round(flops_text(cfg, lens) / 1e9, 2),
+                     "qkv_gemm": committed_qkv_gemm(args)},
     }
     if sync.rank == 0:
         kern, empty_us = time_step_kernels(tr, imgs[0], labs[0])

@@ -344,11 +344,22 @@ class Engine:
         # whose row statistics are over 96 columns instead of 64 (rpo_gemm_args.ln_group): grp says which.
         units = (N, K, Rf)
         which = os.environ.get("RPO_RESID_UNITS", "all")            # A/B switch: all | c_proj | none
+        # SPLIT mode (round 4): when an image's N + K rows do not fit a one-round tile but its N frozen rows do (ViT-B/16
+        # at K = 48: 245 > 224 rows), the frozen rows keep the one-round kernels -- row units of N + 0 rows, rows [0, Rf) --
+        # and the B*K prompt rows take their own launches on the generic tiles, as the last block's always do.  Rows never
+        # mix inside a GEMM, so results are those of the whole-stream launches up to the tile shapes' summation order.
+        # OPT-IN (RPO_SPLIT=1): measured 3 % SLOWER at K = 48, B = 32 (4.287 vs 4.154 ms, two alternating pairs,
+        # profiles/r04_ab_split_k48.txt) -- the four extra 1536-row launches per block (~10 us each) cost more than the
+        # one-round kernels save on the frozen rows.
+        split = self._split_rows(B)
+        Mw = Rf if split else R                                       # rows of the whole-batch ("wide") launches
+        if split:
+            units = (N, 0, Rf)
         u_out, u_proj = (units if which == "all" else None), (units if which in ("all", "c_proj") else None)
-        grps = self._stats_group.get(B)
+        grps = self._stats_group.get((B, split))
         if grps is None:
-            grps = self._stats_group[B] = ((ops.gemm_stats_group(R, dv, dv, self.act, u_out),
-                                            ops.gemm_stats_group(R, dv, 4 * dv, self.act, u_proj)) if fold else (64, 64))
+            grps = self._stats_group[(B, split)] = ((ops.gemm_stats_group(Mw, dv, dv, self.act, u_out),
+                                                     ops.gemm_stats_group(Mw, dv, 4 * dv, self.act, u_proj)) if fold else (64, 64))
         g_out, g_proj = grps                 # statistics written by out-proj (read by c_fc) / by c_proj (read by in-proj)
         # Residual stream as 16-bit hi / lo halves (rpo_gemm_args.resid_hi ...): where both residual GEMMs of a block run on
         # the one-round row-unit kernel, the stream of the whole-batch blocks lives in h (hi = the 16-bit copy the next
@@ -357,7 +368,7 @@ class Engine:
         # block's frozen rows are wanted in fp32 (full_last: forward_plain reads the CLS rows).  A/B: RPO_NO_HILO=1.
         hilo = (fold and not full_last and u_out is not None and u_proj is not None and len(self.vis) > 1
                 and os.environ.get("RPO_NO_HILO") != "1"
-                and ops.gemm_hilo_ok(R, dv, dv, self.act, u_out, g_out) and ops.gemm_hilo_ok(R, dv, 4 * dv, self.act, u_proj, g_proj))
+                and ops.gemm_hilo_ok(Mw, dv, dv, self.act, u_out, g_out) and ops.gemm_hilo_ok(Mw, dv, 4 * dv, self.act, u_proj, g_proj))
         h_lo = self.h_lo[:R]
         # RPO_RESID16=1: the stream as the 16-bit hi half ALONE (no lo half read or written: 22 MB less per residual GEMM
         # again; fp16 mode: step -1.1 %).  In the fp16 mode that is what the reference's own PREC: fp16 run keeps
@@ -367,6 +378,9 @@ class Engine:
         # tolerance row (tests/test_gpu_model.py: RESID16_TOL), not a default.
         if hilo and os.environ.get("RPO_RESID16") == "1":
             h_lo = None
+        # per-row partial statistics live in ONE buffer: rows written with g-column groups start at float offset
+        # row * (dv / g) * 2, so the frozen rows' 96-column records ([0, Rf * 16)) and the prompt rows' 64-column records
+        # ([Rf * 24, R * 24)) of the split mode / the last block never overlap
         stv = lambda grp: self.ln_stats.view(-1)[:R * (dv // grp) * 2].view(R, dv // grp, 2)
         st_out, st_proj, st64 = stv(g_out), stv(g_proj), self.ln_stats[:R]
         last = len(self.vis) - 1
@@ -390,6 +404,7 @@ class Engine:
                 b = self.vis[l]
             return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
                     "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
+        no_probe = lambda name: _NO_PROBE
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
             # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
@@ -399,64 +414,91 @@ class Engine:
                 ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, h)
             w_in, b_in = (blk.w_in_ln, blk.b_in_ln) if folded_in else (blk.w_in, blk.b_in)
             epi_in = EPI_LN_BIAS if folded_in else EPI_BIAS
-            lnk = lambda r0, r1, c0, c1: (dict(ln_stats=st_proj[r0:r1], ln_colsum=blk.s_in[c0:c1], ln_group=g_proj)
-                                          if folded_in else {})
+            # statistics the previous block's c_proj left: over g_proj-column groups where it ran on the wide launch, over 64
+            # where the prompt rows had their own (split mode)
+            lnk = lambda r0, r1, c0, c1, own=False: (dict(ln_stats=(st64 if own else st_proj)[r0:r1], ln_colsum=blk.s_in[c0:c1],
+                                                          ln_group=64 if own else g_proj) if folded_in else {})
             if l < last or full_last:
-                # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
-                with self._timed("in_proj"):
-                    ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv),
-                                prefetch=pf_of("in_", l))
+                if split:
+                    with self._timed("in_proj"):
+                        ops.gemm_nt(h[:Rf], w_in, qkv[:Rf], epi_in, bias=b_in, **lnk(0, Rf, 0, 3 * dv), prefetch=pf_of("in_", l))
+                    # K/V of prompt rows are never read (visual mask, rpo.py:154-156): their q alone
+                    ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv, own=True))
+                else:
+                    # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
+                    with self._timed("in_proj"):
+                        ops.gemm_nt(h, w_in, qkv, epi_in, bias=b_in, skip_row0=Rf, skip_col0=dv, **lnk(0, R, 0, 3 * dv),
+                                    prefetch=pf_of("in_", l))
                 with self._timed("attn_fwd"):
                     ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE)
-                lo = 0
+                segs = [(0, Rf, True), (Rf, R, False)] if split else [(0, R, True)]
             else:
                 # Last block: only its K prompt rows are consumed (ln_post reads x[:, -K:], rpo.py:210; the CLS feature
                 # i_f of :211 is dead code), and no later block reads the frozen rows.  So the frozen rows contribute
                 # their K / V and nothing else: q and everything after attention run on the B*K prompt rows only.
                 ops.gemm_nt(h[:Rf], w_in[dv:], qkv[:Rf, dv:], epi_in, bias=b_in[dv:], **lnk(0, Rf, dv, 3 * dv))
-                ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv))
+                ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv, own=split))
                 ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE,
                                       q_first=N)
-                lo = Rf
-            timed = self._timed if l < last else (lambda name: _NO_PROBE)     # the last block runs on prompt rows only
-            # (unless full_last: forward_plain needs the CLS row of the last block)
-            # the last block works on the prompt rows only: plain tiles, 64-column statistics
-            whole = lo == 0
-            un_o, go, so = (u_out, g_out, st_out) if whole else (None, 64, st64)
-            un_p, gp, sp = (u_proj, g_proj, st_proj) if whole else (None, 64, st64)
-            un = units if whole else None
-            # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
-            prod = dict(out2=h[lo:], ln_stats=so[lo:], ln_group=go) if fold else {}
-            # hi / lo stream: block 0's out-proj still reads the fp32 x[0] (img_embed_norm wrote it) and starts the halves
-            hl = hilo and whole
-            res_o = dict(resid_hi=h, resid_lo=h_lo) if (hl and l > 0) else dict(resid=x[lo:])
-            if hl:
-                prod.update(out_lo=h_lo, c_row0=Rf)             # (h_lo None: the hi half alone)
-            with timed("out_proj"):
-                ops.gemm_nt(att[lo:], blk.w_out, xm[lo:], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
-                            **res_o, **prod, prefetch=pf_of("out", l))
-            if fold:
-                with timed("c_fc"):
-                    ops.gemm_nt(h[lo:], blk.w_fc_ln, g[lo:], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
-                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo,
-                                ln_stats=so[lo:], ln_colsum=blk.s_fc, row_units=un, ln_group=go,
-                                prefetch=pf_of("fc", l))
-            else:
-                with timed("ln_2"):
-                    ops.layernorm_fwd(xm[lo:], blk.ln2_w, blk.ln2_b, h[lo:])
-                with timed("c_fc"):
-                    ops.gemm_nt(h[lo:], blk.w_fc, g[lo:], EPI_BIAS_QGELU, bias=blk.b_fc,
-                                aux=self.u[l][:Rp] if train else None, aux_row0=Rf - lo, row_units=un)
-            # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
-            prod = dict(out2=h[lo:], ln_stats=sp[lo:], ln_group=gp) if (fold and l < last) else {}
-            res_p = dict(resid_hi=h, resid_lo=h_lo) if hl else dict(resid=xm[lo:])
-            if hl:
-                prod.update(out_lo=h_lo, c_row0=Rf)
-            with timed("c_proj"):
-                ops.gemm_nt(g[lo:], blk.w_proj, xo[lo:], EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
-                            **res_p, **prod, prefetch=pf_of("proj", l))
+                segs = [(Rf, R, False)]
+            # the rows after attention: ONE wide launch per GEMM (rows [0, R), or [0, Rf) in the split mode) on the
+            # row-unit kernels, and / or the prompt rows [Rf, R) on plain tiles with 64-column statistics
+            for lo, hi, wide in segs:
+                timed = self._timed if wide else no_probe
+                un_o, go, so = (u_out, g_out, st_out) if wide else (None, 64, st64)
+                un_p, gp, sp = (u_proj, g_proj, st_proj) if wide else (None, 64, st64)
+                un = units if wide else None
+                has_prompt = hi > Rf                                  # rows whose pre-activations the backward needs
+                aux = self.u[l][:Rp] if (train and has_prompt) else None
+                aux_row0 = max(Rf - lo, 0) if has_prompt else hi - lo
+                # out-proj + residual; folded: it also leaves the 16-bit copy of xm in h and its row statistics in st
+                prod = dict(out2=h[lo:hi], ln_stats=so[lo:hi], ln_group=go) if fold else {}
+                # hi / lo stream: block 0's out-proj still reads the fp32 x[0] (img_embed_norm wrote it) and starts the halves
+                hl = hilo and wide
+                res_o = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if (hl and l > 0) else dict(resid=x[lo:hi])
+                if hl:
+                    prod.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)             # (h_lo None: the hi half alone)
+                with timed("out_proj"):
+                    ops.gemm_nt(att[lo:hi], blk.w_out, xm[lo:hi], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
+                                **res_o, **prod, prefetch=pf_of("out", l) if wide else None)
+                if fold:
+                    with timed("c_fc"):
+                        ops.gemm_nt(h[lo:hi], blk.w_fc_ln, g[lo:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                                    aux=aux, aux_row0=aux_row0,
+                                    ln_stats=so[lo:hi], ln_colsum=blk.s_fc, row_units=un, ln_group=go,
+                                    prefetch=pf_of("fc", l) if wide else None)
+                else:
+                    with timed("ln_2"):
+                        ops.layernorm_fwd(xm[lo:hi], blk.ln2_w, blk.ln2_b, h[lo:hi])
+                    with timed("c_fc"):
+                        ops.gemm_nt(h[lo:hi], blk.w_fc, g[lo:hi], EPI_BIAS_QGELU, bias=blk.b_fc,
+                                    aux=aux, aux_row0=aux_row0, row_units=un)
+                # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
+                prod = dict(out2=h[lo:hi], ln_stats=sp[lo:hi], ln_group=gp) if (fold and l < last) else {}
+                res_p = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if hl else dict(resid=xm[lo:hi])
+                if hl:
+                    prod.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)
+                with timed("c_proj"):
+                    ops.gemm_nt(g[lo:hi], blk.w_proj, xo[lo:hi], EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
+                                **res_p, **prod, prefetch=pf_of("proj", l) if wide else None)
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
+
+    def _split_rows(self, B: int) -> bool:
+        """Whether the image forward runs its frozen rows and its prompt rows as separate launches (see _image_forward):
+        16-bit modes with the LayerNorm fold, when the one-round row-unit kernels take an image's N frozen rows but not
+        its N + K rows."""
+        cfg = self.cfg
+        if self.act == torch.float32 or not self.fold_ln or os.environ.get("RPO_SPLIT") != "1" or cfg.K == 0:
+            return False
+        key = ("split", B)
+        if key not in self._stats_group:
+            N, K, dv = cfg.n_frozen, cfg.K, cfg.d_v
+            Rf, R = B * N, B * (N + K)
+            whole = ops.gemm_hilo_ok(R, dv, dv, self.act, (N, K, Rf), ops.gemm_stats_group(R, dv, dv, self.act, (N, K, Rf)))
+            frozen = ops.gemm_hilo_ok(Rf, dv, dv, self.act, (N, 0, Rf), ops.gemm_stats_group(Rf, dv, dv, self.act, (N, 0, Rf)))
+            self._stats_group[key] = bool(frozen and not whole)
+        return self._stats_group[key]
 
     # ------------------------------------------------------------------ backward pieces
     def _rows_backward(self, blocks: List[_Block], x: List[torch.Tensor], xm: List[torch.Tensor],

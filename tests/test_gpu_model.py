@@ -955,6 +955,24 @@ def test_joint_backward_equals_the_two_chains(monkeypatch, B):
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_split_row_launches_match_reference_golden(monkeypatch):
+    """RPO_SPLIT=1 (opt-in, Engine._split_rows): at K = 48 an image's 245 rows do not fit the one-round 224-row tiles, its
+    197 frozen rows do -- they keep the row-unit kernels (units of 197 + 0 rows) and the prompt rows run as their own
+    launches in EVERY block.  Same bounds against the reference's own outputs as the default schedule."""
+    from rpo_amd.custom_clip import CustomCLIP
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_full_k48_b32.npz")))
+    cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 48, 32)
+    monkeypatch.setenv("RPO_SPLIT", "1")
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float16, max_batch=32, prompts=(tp, ip))
+    assert m.engine._split_rows(32)
+    loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) <= F16_LOGIT_ATOL
+    assert _relmax(m.prompt_learner.img_prompt.grad.cpu().numpy(), g["g_img"]) <= F16_GRAD_REL
+    assert _relmax(m.prompt_learner.text_prompt.grad.cpu().numpy(), g["g_text"]) <= F16_GRAD_REL
+
+
 @pytest.mark.parametrize("case", ["d2_k8_b3", "full_b32", "full_b16_f16"])
 def test_persistent_backward_chain_matches_the_launch_chain(monkeypatch, case):
     """rpo_chain_bwd (csrc/chain.hip, opt-in RPO_CHAIN=1): the 7 x layers stages of a tower's prompt-row backward as ONE
