@@ -252,10 +252,10 @@ int rpo_attn_readonly_bwd(const void* q_rows, int64_t ldq, const void* k, const 
                           const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
                           int B, int H, int N, int Kp, float scale, void* stream);
 
-/* The same with the d out-proj GEMM folded in (16-bit storage, d = H * 64 = 512 or 768, Kp <= 32): dx[B*Kp, lddx] is the gradient
- * of the out-proj OUTPUT (act dtype) and w_out_t[d, ldw] the transposed out-proj weight ([in, out], as packed for the
- * dX GEMMs); every (image, head) workgroup forms its slice of da = dx . W_out itself.  Replaces the autograd of
- * out_proj + SDPA (clip/model.py:186) for the prompt rows with one launch. */
+/* The same with the d out-proj GEMM folded in (16-bit storage, d = H * 64 = 512, 768 or 1024, Kp <= 64): dx[B*Kp, lddx] is
+ * the gradient of the out-proj OUTPUT (act dtype) and w_out_t[d, ldw] the transposed out-proj weight ([in, out], as
+ * packed for the dX GEMMs); every (image, head, 32-query tile) workgroup forms its slice of da = dx . W_out itself.
+ * Replaces the autograd of out_proj + SDPA (clip/model.py:186) for the prompt rows with one launch. */
 int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const void* k, const void* v, int64_t ldkv,
                                const void* dx, int64_t lddx, const void* w_out_t, int64_t ldw, void* dq, int64_t lddq,
                                int dtype, int B, int H, int N, int Kp, float scale, void* stream);

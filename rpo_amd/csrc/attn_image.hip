@@ -455,9 +455,13 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
                                               int64_t ldkv, const T* da, int64_t ldda,
                                               T* dq, int64_t lddq, int B, int H, int N, int Kp,
                                               float scale, const T* wo, int64_t ldwo,
-                                              const int32_t* key_len, int key_stride, const bool plain_order = false) {
+                                              const int32_t* key_len, int key_stride, const bool plain_order = false,
+                                              const int nqt_wg = 1) {
   using L = AL<T, NT>;
-  constexpr int stat_off = NCW > 0 && L::BWD_BYTES < 65536 ? 65536 : L::BWD_BYTES;   // launchers allocate stat_off + 2048
+  // fused variant: every wave owns WSLOTS 8-KiB landing slots for its W_out^T chunks (NCW <= 3: two, the third chunk re-uses
+  // slot 0; NCW = 4, d = 1024: four, all requested up front)
+  constexpr int WSLOTS = NCW == 4 ? 4 : 2, WSTRIDE = WSLOTS * 8192;
+  constexpr int stat_off = NCW > 0 && L::BWD_BYTES < 4 * WSTRIDE ? 4 * WSTRIDE : L::BWD_BYTES;   // launchers allocate stat_off + 2048
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -472,7 +476,9 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   }();
 #endif
-  const int b = wgid / H, h = wgid % H;
+  // fused variant with Kp > 32: nqt_wg workgroups per (group, head), one per 32-query tile (adjacent: same XCD)
+  const int pair_id = wgid / nqt_wg, qt_wg = wgid - pair_id * nqt_wg;
+  const int b = pair_id / H, h = pair_id % H;
   if (key_len != nullptr) N = max(1, min(key_len[b], min(key_stride, NT * 32)));   // keys of this group
   else key_stride = N;
   const T* kb = k + (int64_t)b * key_stride * ldkv + h * 64;
@@ -488,8 +494,9 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
   // fused variant: one query tile (the launcher checks Kp <= 32) -- with a runtime trip count hipcc hoists the address
   // arithmetic of every load of the prologue out of the loop and spills it
   const int nqt = NCW > 0 ? 1 : (Kp + 31) / 32;
-  for (int qt = 0; qt < nqt; ++qt) {
-    if (qt > 0) __syncthreads();                   // partials of the previous tile have been consumed
+  for (int qt0 = 0; qt0 < nqt; ++qt0) {
+    if (qt0 > 0) __syncthreads();                  // partials of the previous tile have been consumed
+    const int qt = NCW > 0 ? qt_wg : qt0;
     const int i = qt * 32 + l31;
     const int64_t prow = (int64_t)b * Kp + min(i, Kp - 1);
     RowFrag<T> qf, df;                             // issued ahead of the staging loads: one HBM round trip
@@ -505,7 +512,7 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
       // the MFMAs.  The order of the groups is pinned (counted vmcnt waits below).
       typedef const __attribute__((address_space(1))) void* gptr_t;
       typedef __attribute__((address_space(3))) void* lptr_t;
-      char* myslot = smem + wave * 16384;
+      char* myslot = smem + wave * WSTRIDE;
       const int dr = lane >> 3, dc = lane & 7;
       const char* wsrc = reinterpret_cast<const char*>(wo) + ((int64_t)(h * 64 + dr) * ldwo) * 2 + 128 * wave;
       auto dma_chunk = [&](int c, int slot) {
@@ -520,6 +527,12 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
       asm volatile("" ::: "memory");
       dma_chunk(1, 1);
       asm volatile("" ::: "memory");
+      if constexpr (NCW == 4) {
+        dma_chunk(2, 2);
+        asm volatile("" ::: "memory");
+        dma_chunk(3, 3);
+        asm volatile("" ::: "memory");
+      }
       bf16x8_t xb[NCW][4];
       const T* xrow = da + prow * ldda + half * 8 + 64 * wave;
 #pragma unroll
@@ -550,7 +563,7 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
 #ifdef RPO_FUSED_SAFE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + NXQ) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NCW == 4 ? 24 : 8) + NXQ) : "memory");
 #endif
       mfma_chunk(0, 0);
       if constexpr (NCW == 3) {
@@ -568,9 +581,21 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
 #ifdef RPO_FUSED_SAFE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXQ + (NCW == 3 ? 8 : 0) + 2 * ITERS) : "memory");   // younger than chunk 1
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXQ + (NCW == 3 ? 8 : NCW == 4 ? 16 : 0) + 2 * ITERS) : "memory");   // younger than chunk 1
 #endif
       mfma_chunk(1, 1);
+      if constexpr (NCW == 4) {
+#ifdef RPO_FUSED_SAFE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXQ + 8 + 2 * ITERS) : "memory");                    // younger than chunk 2
+#endif
+        mfma_chunk(2, 2);
+#ifndef RPO_FUSED_SAFE
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXQ + 2 * ITERS) : "memory");                        // younger than chunk 3
+#endif
+        mfma_chunk(3, 3);
+      }
       if constexpr (NCW == 3) {
 #ifdef RPO_FUSED_SAFE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -588,11 +613,12 @@ __device__ __forceinline__ void attn_bwd_body(char* smem, const int bid, const i
                                         dpart[i >> 2][4 * (i & 3) + 2], dpart[i >> 2][4 * (i & 3) + 3]);
       __syncthreads();
       float dfull[32];
-      const float4* pall = reinterpret_cast<const float4*>(smem);   // wave w's partials start at byte 16384 * w
+      const float4* pall = reinterpret_cast<const float4*>(smem);   // wave w's partials start at byte WSTRIDE * w
+      constexpr int PW = WSTRIDE / 16;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float4 a = pall[i * 64 + lane], b = pall[1024 + i * 64 + lane], c = pall[2048 + i * 64 + lane],
-                     d = pall[3072 + i * 64 + lane];
+        const float4 a = pall[i * 64 + lane], b = pall[PW + i * 64 + lane], c = pall[2 * PW + i * 64 + lane],
+                     d = pall[3 * PW + i * 64 + lane];
         dfull[4 * i] = (a.x + b.x) + (c.x + d.x); dfull[4 * i + 1] = (a.y + b.y) + (c.y + d.y);
         dfull[4 * i + 2] = (a.z + b.z) + (c.z + d.z); dfull[4 * i + 3] = (a.w + b.w) + (c.w + d.w);
       }
@@ -734,10 +760,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const T* qr, int64_t l
                                                        int64_t ldkv, const T* da, int64_t ldda,
                                                        T* dq, int64_t lddq, int B, int H, int N, int Kp,
                                                        float scale, const T* wo = nullptr, int64_t ldwo = 0,
-                                                       const int32_t* key_len = nullptr, int key_stride = 0) {
+                                                       const int32_t* key_len = nullptr, int key_stride = 0,
+                                                       int nqt_wg = 1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   attn_bwd_body<T, NT, NCW>(smem, blockIdx.x, gridDim.x, qr, ldq, k, v, ldkv, da, ldda, dq, lddq, B, H, N, Kp, scale, wo,
-                            ldwo, key_len, key_stride);
+                            ldwo, key_len, key_stride, false, nqt_wg);
 }
 
 // Two attention-backward problems (d out-proj folded in) in one launch: workgroups [0, blocks0) are the (image, head)
@@ -795,8 +822,13 @@ int launch_bwd(const void* qr, int64_t ldq, const void* k, const void* v, int64_
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(da), ldda,
                      static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(nullptr), (int64_t)0,
-                     static_cast<const int32_t*>(nullptr), 0);
+                     static_cast<const int32_t*>(nullptr), 0, 1);
   return rpo_launch_status();
+}
+
+constexpr int bwd_proj_lds(int bwd_bytes, int ncw) {
+  const int slots = 4 * (ncw == 4 ? 4 : 2) * 8192;
+  return (bwd_bytes > slots ? bwd_bytes : slots) + 2048;
 }
 
 template <typename T, int NT, int NCW>
@@ -805,37 +837,36 @@ int launch_bwd_proj(const void* qr, int64_t ldq, const void* k, const void* v, i
                     float scale, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT, NCW>;
-  constexpr int bytes = (AL<T, NT>::BWD_BYTES > 65536 ? AL<T, NT>::BWD_BYTES : 65536) + 2048;   // 4 waves x 2 weight slots of 8 KiB + row statistics
+  constexpr int bytes = bwd_proj_lds(AL<T, NT>::BWD_BYTES, NCW);   // 4 waves x 2 (4) weight slots of 8 KiB + row statistics
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
+  const int nqt = (Kp + 31) / 32;                  // one workgroup per (image, head, 32-query tile)
+  hipLaunchKernelGGL(kern, dim3(B * H * nqt), dim3(256), bytes, s, static_cast<const T*>(qr), ldq,
                      static_cast<const T*>(k), static_cast<const T*>(v), ldkv, static_cast<const T*>(dx), lddx,
                      static_cast<T*>(dq), lddq, B, H, N, Kp, scale, static_cast<const T*>(wo), ldwo,
-                     static_cast<const int32_t*>(nullptr), 0);
+                     static_cast<const int32_t*>(nullptr), 0, nqt);
   return rpo_launch_status();
 }
 
 bool ok_ld(int64_t ld, int esz) { return (ld * esz) % 16 == 0; }
-
-constexpr int bwd_proj_lds(int bwd_bytes) { return (bwd_bytes > 65536 ? bwd_bytes : 65536) + 2048; }
 
 // one problem with per-group key counts (the text tower)
 template <typename T, int NT, int NCW>
 int launch_bwd_proj_var(const AttnBwdProblem& a, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_kernel<T, NT, NCW>;
-  constexpr int bytes = bwd_proj_lds(AL<T, NT>::BWD_BYTES);
+  constexpr int bytes = bwd_proj_lds(AL<T, NT>::BWD_BYTES, NCW);
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(256), bytes, s, static_cast<const T*>(a.qr), a.ldq,
                      static_cast<const T*>(a.k), static_cast<const T*>(a.v), a.ldkv, static_cast<const T*>(a.da), a.ldda,
                      static_cast<T*>(a.dq), a.lddq, a.B, a.H, a.N, a.Kp, a.scale, static_cast<const T*>(a.wo), a.ldwo,
-                     a.key_len, a.key_stride);
+                     a.key_len, a.key_stride, 1);
   return rpo_launch_status();
 }
 template <typename T, int NT0, int NCW0, int NT1, int NCW1>
 int launch_bwd_proj_pair(const AttnBwdProblem& a, const AttnBwdProblem& b, hipStream_t s) {
   static rpo_lds_mask_t lds_ok{0};
   auto kern = attn_bwd_pair_kernel<T, NT0, NCW0, NT1, NCW1>;
-  constexpr int b0 = bwd_proj_lds(AL<T, NT0>::BWD_BYTES), b1 = bwd_proj_lds(AL<T, NT1>::BWD_BYTES);
+  constexpr int b0 = bwd_proj_lds(AL<T, NT0>::BWD_BYTES, NCW0), b1 = bwd_proj_lds(AL<T, NT1>::BWD_BYTES, NCW1);
   constexpr int bytes = b0 > b1 ? b0 : b1;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   const int items0 = a.B * a.H, items1 = b.B * b.H, slots = 2 * rpo_cu_count();
@@ -891,6 +922,7 @@ int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void
 #define RPO_BP(NT_, NCW_) return launch_bwd_proj<T, NT_, NCW_>(qr, ldq, k, v, ldkv, dx, lddx, wo, ldwo, dq, lddq, B, H, N, Kp, scale, s)
   if (ncw == 2) { if (big) RPO_BP(9, 2); RPO_BP(7, 2); }
   if (ncw == 3) { if (big) RPO_BP(9, 3); RPO_BP(7, 3); }
+  if (ncw == 4) { if (big) RPO_BP(9, 4); RPO_BP(7, 4); }
 #undef RPO_BP
   return RPO_E_SHAPE;
 }
@@ -962,7 +994,8 @@ extern "C" int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const
   if (!q_rows || !k || !v || !dx || !w_out_t || !dq || B <= 0 || H <= 0 || N <= 0 || Kp <= 0) return RPO_E_BADARG;
   if (dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
   const int d = H * 64;
-  if (N > 288 || Kp > 32 || (d != 512 && d != 768)) return RPO_E_SHAPE;
+  // Kp > 32: one workgroup per 32-query tile (each stages the keys again); d = 1024: four weight slots per wave
+  if (N > 288 || Kp > 64 || (d != 512 && d != 768 && d != 1024)) return RPO_E_SHAPE;
   if (!aligned16(q_rows) || !aligned16(k) || !aligned16(v) || !aligned16(dx) || !aligned16(w_out_t) || !ok_ld(ldq, 2) ||
       !ok_ld(ldkv, 2) || !ok_ld(lddx, 2) || !ok_ld(ldw, 2) || reinterpret_cast<uintptr_t>(dq) % 8 || (lddq * 2) % 8)
     return RPO_E_ALIGN;

@@ -557,8 +557,11 @@ class Engine:
         ops.layernorm_bwd(self.dy_v[0, r0:r1], self.x[-1][Rf + r0:Rf + r1], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
-        # 16-bit modes, K <= 32, d = 512 / 768: the d out-proj GEMM runs inside the attention backward kernel
-        fold_out = (self.act != torch.float32 and K <= 32 and dv in (512, 768)
+        # 16-bit modes, K <= 64, d = 512 / 768 / 1024: the d out-proj GEMM runs inside the attention backward kernel
+        # (round 4: d = 1024 -- ViT-L/14 -- and K in (32, 64] -- one workgroup per 32-query tile; A/B: RPO_BWD_FOLD_R3=1
+        # restores the round-3 coverage)
+        r3 = os.environ.get("RPO_BWD_FOLD_R3") == "1"
+        fold_out = (self.act != torch.float32 and K <= (32 if r3 else 64) and dv in ((512, 768) if r3 else (512, 768, 1024))
                     and os.environ.get("RPO_NO_BWD_FOLD") != "1")
 
         def attn_bwd(l, da, dq):

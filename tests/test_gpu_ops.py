@@ -515,6 +515,22 @@ def test_gemm_layernorm_fold(mode, M, d, N):
     close(outs[0][1], pre[row0:], mode, "LN-folded saved u", tol=1.5 * TOL[mode])
     for cfg in cfgs[1:]:
         assert torch.equal(outs[cfg][0], outs[0][0]) and torch.equal(outs[cfg][1], outs[0][1]), f"tile_config {cfg}"
+    # the form the engine's 16-bit modes save: d quickgelu / du in the act dtype (the 224x384 kernel forms it in its block
+    # loop from the activation's own sigmoid) -- the same bits from every tiling, and with a row stride that sends the
+    # one-round kernel down its separate fp32 pass
+    d16 = {}
+    for cfg in cfgs:
+        for pad in (0, 4):
+            y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+            aux16 = torch.full((M - row0, N + pad), float("nan"), dtype=dt, device=dev())[:, :N]
+            hint = dict(tile_config=10, row_units=(197, 24, 6304)) if cfg == "units" else dict(tile_config=cfg)
+            o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), aux=aux16, aux_row0=row0,
+                      ln_stats=stats, ln_colsum=s.to(dev()), **hint)
+            assert torch.equal(y, outs[0][0]), f"tile_config {cfg}, aux16 pad {pad}"
+            d16[cfg, pad] = aux16
+    close(d16[0, 0], R.qgelu_grad(pre[row0:]), mode, "LN-folded saved derivative", tol=1.5 * TOL[mode])
+    for key, v in d16.items():
+        assert torch.equal(v, d16[0, 0]), f"saved derivative, tile_config / pad {key}"
     y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
     o.gemm_nt(xb, wq.to(dev()), y, L.EPI_LN_BIAS, bias=bq.to(dev()), ln_stats=stats, ln_colsum=s.to(dev()))
     close(y, pre, mode, "LN-folded in-proj", tol=1.5 * TOL[mode])
@@ -642,7 +658,9 @@ def test_attn_readonly_bwd(mode, B, H, N, Kp):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-@pytest.mark.parametrize("B,H,N,Kp", [(2, 12, 197, 24), (3, 8, 50, 7), (1, 12, 257, 32), (2, 8, 197, 1)])
+@pytest.mark.parametrize("B,H,N,Kp", [(2, 12, 197, 24), (3, 8, 50, 7), (1, 12, 257, 32), (2, 8, 197, 1),
+                                      (2, 16, 257, 24), (1, 16, 197, 32),      # d = 1024 (ViT-L/14): four weight slots per wave
+                                      (2, 12, 197, 48), (1, 16, 257, 33), (2, 8, 60, 64)])   # Kp > 32: a workgroup per query tile
 def test_attn_readonly_bwd_with_out_proj_folded_in(mode, B, H, N, Kp):
     """rpo_attn_readonly_bwd_proj: dq from the gradient of the out-proj OUTPUT -- every (image, head) workgroup forms
     da = dx . W_out[:, head] itself.  Against float64 (da rounded to the act dtype as the separate GEMM would), against
@@ -679,9 +697,9 @@ def test_attn_readonly_bwd_with_out_proj_folded_in(mode, B, H, N, Kp):
         o.attn_readonly_bwd_proj(t[Rf:, :d], t[:Rf, d:2 * d], t[:Rf, 2 * d:], dx.to(dev(), dt), w_t, dq3, B, H, N, Kp)
         assert torch.equal(dq3, dq), "not deterministic: LDS race"
     if Kp == 24:
-        with pytest.raises(RPOLibraryError):                               # 33 query rows: two query tiles
-            big = torch.empty((B * 33, d), dtype=dt, device=dev())
-            o.attn_readonly_bwd_proj(big, t[:Rf, d:2 * d], t[:Rf, 2 * d:], big, w_t, big.clone(), B, H, N, 33)
+        with pytest.raises(RPOLibraryError):                               # 65 query rows: three query tiles
+            big = torch.empty((B * 65, d), dtype=dt, device=dev())
+            o.attn_readonly_bwd_proj(big, t[:Rf, d:2 * d], t[:Rf, 2 * d:], big, w_t, big.clone(), B, H, N, 65)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])

@@ -8,7 +8,7 @@ mkdir -p $R/rpo_amd/build/ab
 SRC=${SRC:-gemm}
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $R/rpo_amd/csrc/$SRC.hip -o $R/rpo_amd/build/ab/${SRC}_$name.o
 objs=""
-for o in gemm attn_image attn_text norm misc preprocess; do
+for o in gemm attn_image attn_text norm misc preprocess chain; do
   if [ $o = $SRC ]; then objs="$objs $R/rpo_amd/build/ab/${SRC}_$name.o"; else objs="$objs $R/rpo_amd/build/$o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $R/rpo_amd/build/ab/librpo_$name.so
