@@ -237,7 +237,37 @@ class OracleRPO:
 # the unmasked towers: plain CLIP inference (clip/model.py:344-372), as trainers/zsclip.py:58-63 and the sibling
 # trainers' CustomCLIP.forward (trainers/coop.py:196-208) use them
 # ---------------------------------------------------------------------------
-def plain_clip_forward(state_dict, image, tokens, patch: int, ctx=None):
+def coop_prompts(emb_t: torch.Tensor, tokens: torch.Tensor, ctx: torch.Tensor, class_token_position: str = "end") -> torch.Tensor:
+    """PromptLearner.forward of trainers/coop.py:117-183: the token embeddings `emb_t` [n_cls, T, d] of the
+    "X X .. name." prompts with the n_ctx placeholder slots replaced by `ctx` ([n_ctx, d] generic, expanded over the
+    classes :119-121, or [n_cls, n_ctx, d] class-specific :84-86), the class-name tokens placed per
+    CLASS_TOKEN_POSITION: "end" [SOS | ctx | name . EOT ..] (:126-134), "middle" [SOS | ctx[:n/2] | name | ctx[n/2:] | . EOT ..]
+    (:136-159), "front" [SOS | name | ctx | . EOT ..] (:161-181).  name_len = len(_tokenizer.encode(name)) (:99) = the
+    prompt's EOT index - n_ctx - 2."""
+    n_cls = emb_t.shape[0]
+    n_ctx = ctx.shape[-2]
+    if ctx.dim() == 2:
+        ctx = ctx.unsqueeze(0).expand(n_cls, -1, -1)
+    prefix, suffix = emb_t[:, :1], emb_t[:, 1 + n_ctx:]
+    if class_token_position == "end":
+        return torch.cat([prefix, ctx, suffix], dim=1)
+    name_lens = (tokens.argmax(dim=-1) - n_ctx - 2).tolist()
+    half = n_ctx // 2
+    out = []
+    for i in range(n_cls):
+        nl = int(name_lens[i])
+        cls_i, suf_i = suffix[i:i + 1, :nl], suffix[i:i + 1, nl:]
+        if class_token_position == "middle":
+            parts = [prefix[i:i + 1], ctx[i:i + 1, :half], cls_i, ctx[i:i + 1, half:], suf_i]
+        elif class_token_position == "front":
+            parts = [prefix[i:i + 1], cls_i, ctx[i:i + 1], suf_i]
+        else:
+            raise ValueError(class_token_position)
+        out.append(torch.cat(parts, dim=1))
+    return torch.cat(out, dim=0)
+
+
+def plain_clip_forward(state_dict, image, tokens, patch: int, ctx=None, class_token_position: str = "end"):
     """CLIP.forward(image, text) -> (logits_per_image [B, n_cls], image_features [B, e], text_features [n_cls, e]);
     features before normalisation.  Image tower: every token reads every token (clip/model.py:227-240); text tower:
     causal mask over the whole context (:287-292, :347-360), feature at the EOT position (= argmax of the ids).
@@ -259,7 +289,7 @@ def plain_clip_forward(state_dict, image, tokens, patch: int, ctx=None):
     emb_t = sd["token_embedding.weight"][tokens]
     if ctx is not None:
         ctx = ctx if isinstance(ctx, torch.Tensor) else _t(ctx).float()
-        emb_t = torch.cat([emb_t[:, :1], ctx.unsqueeze(0).expand(emb_t.shape[0], -1, -1), emb_t[:, 1 + ctx.shape[0]:]], dim=1)
+        emb_t = coop_prompts(emb_t, tokens, ctx, class_token_position)
     t = (emb_t + sd["positional_embedding"]).permute(1, 0, 2)
     T = t.shape[0]
     causal = torch.full((T, T), float("-inf")).triu_(1)
@@ -272,10 +302,11 @@ def plain_clip_forward(state_dict, image, tokens, patch: int, ctx=None):
     return sd["logit_scale"].exp() * a @ b.t(), img_f, txt_f
 
 
-def coop_loss_and_grad(state_dict, image, tokens, ctx, label, patch: int):
-    """trainers/coop.py:266-270 (fp32 branch): logits, cross-entropy and d loss / d ctx."""
+def coop_loss_and_grad(state_dict, image, tokens, ctx, label, patch: int, class_token_position: str = "end"):
+    """trainers/coop.py:266-270 (fp32 branch): logits, cross-entropy and d loss / d ctx (ctx [n_ctx, d] or, class-specific,
+    [n_cls, n_ctx, d])."""
     c = _t(ctx).float().clone().requires_grad_(True)
-    logits, _, _ = plain_clip_forward(state_dict, image, tokens, patch, ctx=c)
+    logits, _, _ = plain_clip_forward(state_dict, image, tokens, patch, ctx=c, class_token_position=class_token_position)
     loss = F.cross_entropy(logits, _t(label).long())
     loss.backward()
     return logits.detach(), loss.detach(), c.grad.clone()

@@ -8,9 +8,11 @@ without the read-only mask.
 
 Unlike RPO's prompts, a context vector is read by every later token, so its gradient needs the DENSE text-tower backward
 (all tokens of all classes, causal attention with dK / dV): `Engine.coop_forward_backward`.  The image tower is plain
-frozen CLIP and is only run forward.  Generic context (CSC = False) and class token at the end -- the reference's own
-defaults (configs/trainers/CoOp/vit_b16_ep50.yaml) -- are what is built; "middle" / "front" raise in the reference
-config used here as well (its code path for them exists but is not exercised by the repo's scripts).
+frozen CLIP and is only run forward.  The reference's defaults (configs/trainers/CoOp/vit_b16_ep50.yaml) are a generic
+context (CSC = False) with the class token at the end; its other options are built too (round 4): class-specific contexts
+(`csc=True`, :84-86), `class_token_position` "middle" / "front" (:136-183), `ctx_init` word embeddings (:72-80) and
+the `amp` precision branch (:250, :263-270 -- what is left of GradScaler when gradients are fp32: a step whose gradient
+holds Inf / NaN is skipped, as `RPO(amp=True)`).
 
 CoCoOp (`trainers/cocoop.py`: PromptLearner :60-153, CustomCLIP :156-192, trainer :255-275) adds a meta-net on the
 normalised image feature whose output shifts the context PER IMAGE, so every image has its own text features for every
@@ -23,6 +25,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -30,7 +34,7 @@ from . import ops
 from .config import RPOConfig
 from .custom_clip import config_from_state_dict
 from .engine import Engine
-from .trainer import OptimConfig, lr_at_epoch
+from .trainer import OptimConfig, load_checkpoint_file, lr_at_epoch, write_checkpoint
 
 
 class CoOpPromptLearner:
@@ -59,25 +63,47 @@ class CoOpPromptLearner:
         return {"ctx": self.ctx.detach().cpu().clone(), "token_prefix": self.token_prefix.clone(),
                 "token_suffix": self.token_suffix.clone()}
 
+    def named_parameters(self):
+        """(name, device tensor) of what is trained, in the order of the engine's flat parameter buffer -- which is the
+        order torch.optim.SGD numbers them in a checkpoint's optimizer state."""
+        yield "ctx", self.engine.coop_ctx
+
+
+def _init_ctx(cfg: RPOConfig, n_cls: int, n_ctx: int, csc: bool, ctx, ctx_init, token_embedding) -> np.ndarray:
+    """trainers/coop.py:72-91: `ctx_init` = [n_words, d_t] embeddings of the initialisation words (the reference embeds
+    `clip.tokenize(CTX_INIT)` and takes rows 1 .. n_ctx, :76-80; the tokenizer is out of scope here, so the caller passes
+    either those rows or the words' token ids); else N(0, 0.02) from torch's global generator in the reference's shape
+    -- [n_cls, n_ctx, d] for class-specific contexts (:84-86), [n_ctx, d] otherwise (:87-88)."""
+    if ctx is not None:
+        return np.asarray(ctx, dtype=np.float32)
+    if ctx_init is not None:
+        ci = np.asarray(ctx_init)
+        if ci.ndim == 1:                                                     # token ids of the words
+            ci = np.asarray(token_embedding)[ci.astype(np.int64)]
+        assert ci.shape == (n_ctx, cfg.d_t), "ctx_init: n_ctx word embeddings (or their token ids)"
+        assert not csc, "trainers/coop.py:72-80: CTX_INIT gives one generic context"
+        return ci.astype(np.float32)
+    shape = (n_cls, n_ctx, cfg.d_t) if csc else (n_ctx, cfg.d_t)
+    return torch.empty(*shape).normal_(std=0.02).numpy()
+
 
 class CoOpCustomCLIP:
     """`trainers/coop.py:CustomCLIP`: `model(image)` -> logits [B, n_cls] (fp32, on the device)."""
 
     def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int,
                  device: str | torch.device = "cuda:0", act_dtype: torch.dtype = torch.float16, max_batch: int = 32,
-                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None):
+                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None, csc: bool = False,
+                 class_token_position: str = "end", ctx_init: Optional[np.ndarray] = None):
         tokens = np.asarray(tokenized_prompts, dtype=np.int64)
         if cfg is None:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])     # one (unused) RPO prompt row per image
         self.cfg = cfg
         self.engine = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
         with torch.cuda.device(self.engine.dev):
-            self.engine.coop_setup(n_ctx)
-            if ctx is None:
-                # "Initializing a generic context": nn.init.normal_(ctx_vectors, std=0.02) from torch's global generator
-                # (trainers/coop.py:87-88) -- the same draw, so a seeded run starts from the reference's vectors
-                ctx = torch.empty(n_ctx, cfg.d_t).normal_(std=0.02).numpy()
-            self.engine.coop_ctx.copy_(torch.as_tensor(np.asarray(ctx, dtype=np.float32)))
+            self.engine.coop_setup(n_ctx, csc=csc, class_token_position=class_token_position)
+            # (random: the reference's own draw from torch's global generator, so a seeded run starts from its vectors)
+            ctx = _init_ctx(cfg, tokens.shape[0], n_ctx, csc, ctx, ctx_init, state_dict["token_embedding.weight"])
+            self.engine.coop_ctx.copy_(torch.as_tensor(ctx).reshape(self.engine.coop_ctx.shape))
         self.prompt_learner = CoOpPromptLearner(self.engine, n_ctx, state_dict["token_embedding.weight"], tokens)
         self.tokenized_prompts = tokens
 
@@ -96,9 +122,15 @@ class CoOp:
     def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int = 16,
                  optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
                  act_dtype: torch.dtype = torch.float16, batch_size: int = 32, num_batches: int = 1,
-                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None, use_graph: bool = False):
+                 ctx: Optional[np.ndarray] = None, cfg: Optional[RPOConfig] = None, use_graph: bool = False,
+                 csc: bool = False, class_token_position: str = "end", ctx_init: Optional[np.ndarray] = None,
+                 amp: bool = False):
         self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=50)       # configs/trainers/CoOp/vit_b16_ep50.yaml
-        self.model = CoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, cfg)
+        self.model = CoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, cfg,
+                                    csc=csc, class_token_position=class_token_position, ctx_init=ctx_init)
+        self._init_common(batch_size, num_batches, use_graph, amp)
+
+    def _init_common(self, batch_size: int, num_batches: int, use_graph: bool, amp: bool) -> None:
         self.engine, self.cfg = self.model.engine, self.model.cfg
         self.device = self.engine.dev
         self.batch_size, self.num_batches = batch_size, num_batches
@@ -106,12 +138,85 @@ class CoOp:
         self.lr = lr_at_epoch(self.optim_cfg, 0)
         self.use_graph = use_graph
         self._graph = None                               # (HIP graph of one step, the learning rate it was captured with)
+        # PREC "amp" (trainers/coop.py:250, :263-270; trainers/cocoop.py:239, :256-263): logits, loss and gradients are
+        # fp32 here, so GradScaler's scale / unscale has nothing to act on; what is left of it is skipping a step whose
+        # gradient holds Inf / NaN (rpo_sgd_step_guarded: one workgroup scans the gradients, updates only if all finite)
+        self.amp = amp
+        self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device) if amp else None
+        self.best_result = -float("inf")
+
+    def _forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
+        self.engine.coop_forward_backward(image, label)
 
     def _enqueue(self, image: torch.Tensor, label: torch.Tensor) -> None:
         eng, oc = self.engine, self.optim_cfg
-        eng.coop_forward_backward(image, label)
-        ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
-                     first_step=(self._steps == 0))
+        self._forward_backward(image, label)
+        if self.amp:
+            ops.sgd_step_guarded(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay,
+                                 1.0, first_step=(self._steps == 0), found_inf=self._found_inf)
+        else:
+            ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
+                         first_step=(self._steps == 0))
+
+    @property
+    def skipped_steps(self) -> int:
+        """amp: steps GradScaler would have skipped so far (a device read)."""
+        return int(self._found_inf[1].item()) if self.amp else 0
+
+    # -- checkpoints in Dassl's layout (the reader: trainers/coop.py:283-325 / trainers/cocoop.py:277-314) ---------------
+    def save_model(self, directory: str, epoch: Optional[int] = None, is_best: bool = False,
+                   val_result: Optional[float] = None) -> str:
+        """`<directory>/prompt_learner/model.pth.tar-<epoch>` (+ `model-best.pth.tar`) with `state_dict` (ctx, the
+        meta-net for CoCoOp, and the token_prefix / token_suffix buffers the reference's module registers, :100-101),
+        `epoch`, `optimizer` (torch.optim.SGD's state-dict layout, parameters in `named_parameters` order)."""
+        epoch = self.epoch if epoch is None else epoch
+        pl = self.model.prompt_learner
+        state, off, oc = {}, 0, self.optim_cfg
+        names = [n for n, _ in pl.named_parameters()]
+        if self._steps > 0:
+            m = self.engine.coop_moms.detach().cpu()
+            for i, (_, t) in enumerate(pl.named_parameters()):
+                state[i] = {"momentum_buffer": m[off:off + t.numel()].reshape(t.shape).clone()}
+                off += t.numel()
+        group = {"lr": self.lr, "momentum": oc.momentum, "dampening": 0, "weight_decay": oc.weight_decay, "nesterov": False,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None, "initial_lr": oc.lr,
+                 "params": list(range(len(names)))}
+        ck = {"state_dict": pl.state_dict(), "epoch": int(epoch), "optimizer": {"state": state, "param_groups": [group]},
+              "scheduler": {"last_epoch": int(epoch)}, "val_result": val_result, "steps": int(self._steps)}
+        return write_checkpoint(directory, ck, epoch, is_best)
+
+    def load_model(self, directory: str, epoch: Optional[int] = None) -> None:
+        """trainers/coop.py:283-325: `model-best.pth.tar` unless an epoch is named; token_prefix / token_suffix are
+        dropped (:315-320: they belong to the class names the checkpoint was trained on); load_state_dict(strict=False)."""
+        if not directory:
+            print("Note that load_model() is skipped as no pretrained model is given")
+            return
+        model_file = "model-best.pth.tar" if epoch is None else f"model.pth.tar-{epoch}"
+        model_path = os.path.join(directory, "prompt_learner", model_file)
+        if not os.path.exists(model_path):
+            raise FileNotFoundError(f'Model not found at "{model_path}"')
+        ck = load_checkpoint_file(model_path)
+        sd = dict(ck["state_dict"])
+        for k in ("token_prefix", "token_suffix"):
+            sd.pop(k, None)
+        print(f'Loading weights to prompt_learner from "{model_path}" (epoch = {ck["epoch"]})')
+        params = list(self.model.prompt_learner.named_parameters())
+        with torch.no_grad():
+            for name, p in params:
+                if name in sd:
+                    p.copy_(torch.as_tensor(sd[name]).to(p.dtype).reshape(p.shape))
+        st = (ck.get("optimizer") or {}).get("state") or {}
+        try:
+            bufs = [st[i]["momentum_buffer"] for i in range(len(params))]
+            flat = torch.cat([torch.as_tensor(b).reshape(-1).float() for b in bufs])
+            if flat.numel() == self.engine.coop_moms.numel():
+                self.engine.coop_moms.copy_(flat)
+                self._steps = max(1, int(ck.get("steps", 1)))
+        except (KeyError, TypeError, RuntimeError):
+            pass                                                     # a checkpoint without momentum: start it from zero
+        self.epoch = int(ck.get("epoch", 0))
+        self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
+        self._graph = None
 
     def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         """One optimisation step, nothing synchronised; returns the device loss scalar.  With use_graph the ~250 launches
@@ -170,6 +275,12 @@ class CoOp:
 class CoCoOpPromptLearner(CoOpPromptLearner):
     """`trainers/cocoop.py:PromptLearner`: ctx + meta_net (linear1 [e/16, e] -> ReLU -> linear2 [d_t, e/16], :93-97)."""
 
+    def named_parameters(self):
+        yield "ctx", self.engine.coop_ctx
+        for name, t in zip(("meta_net.linear1.weight", "meta_net.linear1.bias", "meta_net.linear2.weight",
+                            "meta_net.linear2.bias"), self.engine.meta):
+            yield name, t
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         w1, b1, w2, b2 = (t.detach().cpu().clone() for t in self.engine.meta)
         return {"ctx": self.ctx.detach().cpu().clone(), "meta_net.linear1.weight": w1, "meta_net.linear1.bias": b1,
@@ -184,7 +295,7 @@ class CoCoOpCustomCLIP:
     def __init__(self, state_dict: Dict[str, np.ndarray], tokenized_prompts: np.ndarray, n_ctx: int,
                  device: str | torch.device = "cuda:0", act_dtype: torch.dtype = torch.float16, max_batch: int = 1,
                  ctx: Optional[np.ndarray] = None, meta: Optional[Dict[str, np.ndarray]] = None,
-                 cfg: Optional[RPOConfig] = None):
+                 cfg: Optional[RPOConfig] = None, ctx_init: Optional[np.ndarray] = None):
         tokens = np.asarray(tokenized_prompts, dtype=np.int64)
         if cfg is None:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])
@@ -194,8 +305,9 @@ class CoCoOpCustomCLIP:
         h = e // 16                                                          # vis_dim // 16 (:94)
         with torch.cuda.device(eng.dev):
             eng.coop_setup(n_ctx, replicas=max_batch, meta_hidden=h)
-            if ctx is None:                                                  # the reference's draws, in its order:
-                ctx = torch.empty(n_ctx, dt).normal_(std=0.02).numpy()       # nn.init.normal_(ctx_vectors, std=0.02) (:83-84)
+            # the reference's draws, in its order: nn.init.normal_(ctx_vectors, std=0.02) (:83-84) or the CTX_INIT words
+            # (:72-80, configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1_ctxv1.yaml: "a photo of a") ...
+            ctx = _init_ctx(cfg, tokens.shape[0], n_ctx, False, ctx, ctx_init, state_dict["token_embedding.weight"])
             if meta is None:                                                 # then nn.Linear's default initialisation
                 l1, l2 = torch.nn.Linear(e, h), torch.nn.Linear(h, dt)
                 meta = dict(w1=l1.weight.detach().numpy(), b1=l1.bias.detach().numpy(),
@@ -213,7 +325,16 @@ class CoCoOpCustomCLIP:
             if self.prompt_learner.training and label is not None:
                 eng.cocoop_forward_backward(image, label.to(eng.dev, dtype=torch.int64))
                 return eng.loss[0]
-            return eng.cocoop_forward_backward(image, None)
+            # inference: the reference tests at batch 100 (configs/trainers/CoCoOp/*.yaml TEST.BATCH_SIZE) with a model
+            # built for training at batch 1 -- every image has its own prompts, so a batch is walked in chunks of the
+            # `replicas` the engine was set up with
+            R, B = eng.coop_replicas, image.shape[0]
+            if B <= R:
+                return eng.cocoop_forward_backward(image, None)
+            out = torch.empty(B, self.cfg.n_cls, dtype=torch.float32, device=eng.dev)
+            for b0 in range(0, B, R):
+                out[b0:b0 + R].copy_(eng.cocoop_forward_backward(image[b0:b0 + R], None))
+            return out
 
 
 class CoCoOp(CoOp):
@@ -224,22 +345,15 @@ class CoCoOp(CoOp):
                  optim: Optional[OptimConfig] = None, device: str | torch.device = "cuda:0",
                  act_dtype: torch.dtype = torch.float16, batch_size: int = 1, num_batches: int = 1,
                  ctx: Optional[np.ndarray] = None, meta: Optional[Dict[str, np.ndarray]] = None,
-                 cfg: Optional[RPOConfig] = None, use_graph: bool = False):
+                 cfg: Optional[RPOConfig] = None, use_graph: bool = False, ctx_init: Optional[np.ndarray] = None,
+                 amp: bool = False):
         self.optim_cfg = optim or OptimConfig(lr=0.002, max_epoch=10)    # configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1.yaml
-        self.model = CoCoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, meta, cfg)
-        self.engine, self.cfg = self.model.engine, self.model.cfg
-        self.device = self.engine.dev
-        self.batch_size, self.num_batches = batch_size, num_batches
-        self.epoch = self.batch_idx = self._steps = 0
-        self.lr = lr_at_epoch(self.optim_cfg, 0)
-        self.use_graph = use_graph
-        self._graph = None
+        self.model = CoCoOpCustomCLIP(state_dict, tokenized_prompts, n_ctx, device, act_dtype, batch_size, ctx, meta, cfg,
+                                      ctx_init=ctx_init)
+        self._init_common(batch_size, num_batches, use_graph, amp)
 
-    def _enqueue(self, image: torch.Tensor, label: torch.Tensor) -> None:
-        eng, oc = self.engine, self.optim_cfg
-        eng.cocoop_forward_backward(image, label)
-        ops.sgd_step(eng.coop_params, eng.coop_grads, eng.coop_moms, self.lr, oc.momentum, oc.weight_decay, 1.0,
-                     first_step=(self._steps == 0))
+    def _forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
+        self.engine.cocoop_forward_backward(image, label)
 
     def forward_backward(self, batch) -> Dict[str, float]:
         eng, oc = self.engine, self.optim_cfg

@@ -303,7 +303,7 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
 }
 
 // ---- forward ---------------------------------------------------------------------------
-template <typename T, int NT>
+template <typename T, int NT, bool TWO_PASS = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, int64_t ld, T* out,
                                                        int64_t ldo, int B, int H, int N, int Kp, float scale,
@@ -396,6 +396,39 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    if constexpr (TWO_PASS) {
+      // EXPERIMENT (round 4): exact two-pass softmax at the SAME register budget (two workgroups per CU): pass 1
+      // recomputes nothing but the row maximum (4 MFMAs + 10 VALU per key tile, one cross-half exchange per QUERY tile),
+      // pass 2 recomputes the scores and has no running maximum, no rescale of the output tile.  VALU per key tile
+      // 115 -> ~75, MFMAs 8 -> 12.
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
+        if (32 * t + 32 > N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[r] = key < N ? sc[r] : -INFINITY;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
+        if (32 * t + 32 > N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[r] = key < N ? sc[r] : -INFINITY;
+          }
+        }
+        l += exp_tile<T>(sc, m, scale);
+        contract_keys<T, NT>(vs, t, sc, o, l31v, half);
+      }
+    } else
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
       // (issuing the score tile of key tile t+1 before the softmax arithmetic of tile t -- one more live tile, 118 VGPRs --
@@ -413,6 +446,135 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    if (s < S && s >= q_first) {
+      T* orow = out + grow * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
+                        o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+    }
+    RPO_STAMP(6);
+  }
+#ifdef RPO_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(7);
+}
+
+// ---- forward, 16-bit storage, round 4: every score tile of a query tile in registers, exact two-pass softmax ----------
+// The online-softmax loop above is one dependent chain per key tile (4 score MFMAs on one accumulator -> max -> cross-half
+// exchange -> exp -> rescale of the output tile -> 4 P.V MFMAs): ~1.4 k cycles per key tile for a wave, 9.7 k per
+// workgroup (profiles/r03_attn_timeline.txt), whatever else the CU does.  With N <= 288 keys a lane's whole score row is
+// only NT x 16 registers, so here a wave first issues ALL NT score tiles (independent accumulators: the MFMAs pipeline),
+// takes the row maximum ONCE (one cross-half exchange per query tile instead of one per key tile), then exponentiates
+// and contracts tile by tile with nothing to rescale.  ~200 VGPRs: one 8-wave workgroup per CU instead of two.
+template <typename T, int NT>
+__global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, int64_t ld, T* out,
+                                                        int64_t ldo, int B, int H, int N, int Kp, float scale,
+                                                        int q_first) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = AL<T, NT>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wgid = [&] {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  }();
+  const int b = wgid / H, h = wgid % H;
+  const T* kb = k + (int64_t)b * N * ld + h * 64;
+  const T* vb = v + (int64_t)b * N * ld + h * 64;
+  char* ks = smem;
+  char* vs = smem + L::K_BYTES;
+  const int S = N + Kp;
+  RPO_STAMP(0);
+  auto qrow = [&](int qt) -> int64_t {
+    const int sc = min(qt * 32 + l31, S - 1);
+    return sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
+  };
+  RowFrag<T> qf;
+  const int qt0 = q_first >> 5;
+  qf.load(q + qrow(qt0 + wave) * ld + h * 64, half);
+  {
+    bf16x8_t vrows[(NT + 7) / 8][4];
+#pragma unroll
+    for (int ti = 0; ti < (NT + 7) / 8; ++ti) {
+      const int key = 32 * (wave + 8 * ti) + l31;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (wave + 8 * ti < NT && key < N) z = *reinterpret_cast<const uint4*>(vb + (int64_t)key * ld + kk * 16 + half * 8);
+        vrows[ti][kk] = __builtin_bit_cast(bf16x8_t, z);
+      }
+    }
+    stage_rows_bf16<NT, 512>(ks, reinterpret_cast<const bf16_t*>(kb), ld, N, tid);
+    RPO_STAMP(1);
+    const bf16x8_t i0 = ident_frag<T>(0, l31, half), i1 = ident_frag<T>(1, l31, half);
+#pragma unroll
+    for (int ti = 0; ti < (NT + 7) / 8; ++ti) {
+      const int t = wave + 8 * ti;
+      if (t < NT) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t fr[2];
+          transpose_tile<T>(vrows[ti], dt, i0, i1, fr);
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2)
+            *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
+        }
+      }
+    }
+  }
+  RPO_STAMP(2);
+  __syncthreads();
+  RPO_STAMP(3);
+  const float c = scale * LOG2E;
+  for (int qt = qt0 + wave; qt * 32 < S; qt += 8) {
+    int l31v = l31;
+    asm volatile("" : "+v"(l31v));
+    const int s = qt * 32 + l31;
+    const int64_t grow = qrow(qt);
+    if (qt != qt0 + wave) qf.load(q + grow * ld + h * 64, half);
+    // pass 1: all score tiles (S^T = K . Q^T: a lane holds 16 of the 32 keys of every tile for ONE query)
+    f32x16_t sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sc[t] = tile_times_frag<T>(ks, t, qf, l31v, half);
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (32 * t + 32 > N) {                       // (uniform) keys >= N of a tile that can hold padding -> -inf
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+          sc[t][r] = key < N ? sc[t][r] : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));           // finite: tile 0 always holds keys
+    RPO_STAMP(4);
+    // pass 2: p = exp((s - m) * scale), row sum, O += V^T-contraction -- nothing to rescale
+    const float mc = m * c;
+    float l = 0.f;
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c, -mc)); l += sc[t][r]; }
+      contract_keys<T, NT>(vs, t, sc[t], o, l31v, half);
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    RPO_STAMP(5);
     if (s < S && s >= q_first) {
       T* orow = out + grow * ldo + h * 64;
 #pragma unroll
@@ -800,10 +962,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const AttnBwdProb
 }
 
 template <typename T, int NT>
+int launch_fwd2(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
+                int N, int Kp, float scale, int q_first, hipStream_t s) {
+  static rpo_lds_mask_t lds_ok{0};
+  auto kern = attn_fwd2_kernel<T, NT>;
+  constexpr int bytes = AL<T, NT>::FWD_BYTES;
+  if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),
+                     static_cast<const T*>(k), static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H,
+                     N, Kp, scale, q_first);
+  return rpo_launch_status();
+}
+
+template <typename T, int NT>
 int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* out, int64_t ldo, int B, int H,
                int N, int Kp, float scale, int q_first, hipStream_t s) {
+#ifdef RPO_ATTN_FWD_V2            // (A/B build: every score tile in registers, one workgroup per CU -- attn_fwd2_kernel)
+  if constexpr (sizeof(T) == 2) return launch_fwd2<T, NT>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+#endif
   static rpo_lds_mask_t lds_ok{0};
+#ifdef RPO_ATTN_FWD_2PASS         // (A/B build: two-pass softmax with recomputed scores, two workgroups per CU)
+  auto kern = attn_fwd_kernel<T, NT, sizeof(T) == 2>;
+#else
   auto kern = attn_fwd_kernel<T, NT>;
+#endif
   constexpr int bytes = AL<T, NT>::FWD_BYTES;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),

@@ -168,6 +168,9 @@ class Engine:
         tx = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][None]
         self.text_x_frozen = self._f32(tx[:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
         self.text_pos = self._f32(sd["positional_embedding"][:self.Lmax])
+        # the token embeddings alone (CoOp's "middle" / "front" class-token positions re-order them before the positional
+        # embedding is added, trainers/coop.py:136-183)
+        self.text_tok = self._f32(sd["token_embedding.weight"][tokens][:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
 
     # ------------------------------------------------------------------ workspace
     def _alloc(self) -> None:
@@ -825,7 +828,35 @@ class Engine:
         return self.logits[:B]
 
     # ------------------------------------------------------------------ CoOp / CoCoOp: training context vectors
-    def coop_setup(self, n_ctx: int, replicas: int = 1, meta_hidden: int = 0) -> None:
+    def coop_layout(self, n_ctx: int, class_token_position: str = "end"):
+        """Where CoOp's PromptLearner.forward (trainers/coop.py:117-183) puts things: for every class c and sequence
+        position p, `src[c, p]` = the position of the "X X .. name." prompt whose TOKEN embedding sits there (-1 where a
+        context vector sits) and `ctx_pos[c, j]` = the position of context vector j.  "end": [SOS | ctx | name . EOT];
+        "middle": [SOS | ctx[:n/2] | name | ctx[n/2:] | . EOT]; "front": [SOS | name | ctx | . EOT].  name_len of a class
+        = its prompt length - n_ctx - 3 (SOS, '.', EOT), i.e. `len(_tokenizer.encode(name))` (:99)."""
+        assert class_token_position in ("end", "middle", "front"), class_token_position    # `else: raise ValueError`, :185
+        n, L = self.cfg.n_cls, self.Lmax
+        src = np.tile(np.arange(L, dtype=np.int64), (n, 1))
+        ctx_pos = np.zeros((n, n_ctx), dtype=np.int64)
+        half = n_ctx // 2
+        for c in range(n):
+            nl = int(self.len_np[c]) - n_ctx - 3
+            assert nl >= 1, "tokens must be the ids of the 'X X .. name.' prompts with n_ctx placeholders"
+            name = np.arange(1 + n_ctx, 1 + n_ctx + nl)
+            if class_token_position == "end":
+                cp = np.arange(1, 1 + n_ctx)
+            elif class_token_position == "middle":
+                cp = np.concatenate([np.arange(1, 1 + half), np.arange(1 + half + nl, 1 + n_ctx + nl)])
+                src[c, 1 + half:1 + half + nl] = name
+            else:
+                cp = np.arange(1 + nl, 1 + nl + n_ctx)
+                src[c, 1:1 + nl] = name
+            src[c, cp] = -1
+            ctx_pos[c] = cp
+        return src, ctx_pos
+
+    def coop_setup(self, n_ctx: int, replicas: int = 1, meta_hidden: int = 0, csc: bool = False,
+                   class_token_position: str = "end") -> None:
         """Buffers of the sibling trainers CoOp (trainers/coop.py) and CoCoOp (trainers/cocoop.py): the learned context
         `coop_ctx` [n_ctx, d_t] and, per text block, everything the DENSE text-tower backward re-reads -- the gradient of a
         context vector flows through every token of every class (plain causal mask), unlike RPO's prompts.
@@ -844,21 +875,34 @@ class Engine:
         au = f32 if act == torch.float32 else a
         Lt, h = cfg.layers_t, meta_hidden
         self.coop_n_ctx, self.coop_replicas, self.coop_hidden = n_ctx, replicas, h
-        sizes = [n_ctx * dt] + ([h * e, h, dt * h, dt] if h else [])
+        # class-specific contexts (TRAINER.COOP.CSC, trainers/coop.py:84-86): ctx [n_cls, n_ctx, d_t] instead of one
+        # [n_ctx, d_t] expanded over the classes (:119-121) -- no sum over the classes in the backward
+        assert not (csc and (replicas > 1 or h)), "class-specific contexts are CoOp's (CoCoOp's context is generic)"
+        self.coop_csc, self.coop_position = bool(csc), class_token_position
+        nctx_rows = (n if csc else 1) * n_ctx
+        src, ctx_pos = self.coop_layout(n_ctx, class_token_position)
+        rows = np.arange(n)[:, None] * L
+        # gather map of the token embeddings (context slots read row 0 and are overwritten) and the rows / positions of
+        # the context vectors, class-major
+        self.c_src_rows = torch.as_tensor((rows + np.maximum(src, 0)).reshape(-1), device=dev)
+        self.c_ctx_rows_idx = torch.as_tensor((rows + ctx_pos).reshape(-1), device=dev)
+        self.c_ctx_pos = torch.as_tensor(ctx_pos.reshape(-1), device=dev)
+        sizes = [nctx_rows * dt] + ([h * e, h, dt * h, dt] if h else [])
         tot = sum(sizes)
         self.coop_params = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.coop_grads = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.coop_moms = torch.zeros(tot, dtype=torch.float32, device=dev)
         offs = np.cumsum([0] + sizes)
         view = lambda buf, i, *shape: buf[offs[i]:offs[i + 1]].view(*shape)
-        self.coop_ctx, self.coop_grad = view(self.coop_params, 0, n_ctx, dt), view(self.coop_grads, 0, n_ctx, dt)
+        cshape = (n, n_ctx, dt) if csc else (n_ctx, dt)
+        self.coop_ctx, self.coop_grad = view(self.coop_params, 0, *cshape), view(self.coop_grads, 0, *cshape)
         if h:
             shapes = [(h, e), (h,), (dt, h), (dt,)]
             self.meta = [view(self.coop_params, i + 1, *sh) for i, sh in enumerate(shapes)]          # w1, b1, w2, b2
             self.meta_grad = [view(self.coop_grads, i + 1, *sh) for i, sh in enumerate(shapes)]
             self.c_fn, self.c_hid, self.c_bias, self.c_dbias = f32(replicas, e), f32(replicas, h), f32(replicas, dt), f32(replicas, dt)
-        self.c_shift = f32(replicas, n_ctx, dt)                       # the context each replica's classes carry
-        self.c_dshift = f32(replicas, n_ctx, dt)
+        self.c_shift = f32(replicas, nctx_rows, dt)                   # the context each replica's classes carry
+        self.c_dshift = f32(replicas, nctx_rows, dt)
         self.c_len = self.len_i32.repeat(replicas).contiguous()
         self.cx = [f32(Rf, dt) for _ in range(Lt + 1)]
         self.cxm = [f32(Rf, dt) for _ in range(Lt)]
@@ -891,8 +935,19 @@ class Engine:
         nv = R * n
         Rf = nv * L
         x0 = self.cx[0][:Rf]
-        x0.view(R, n * L, dt).copy_(self.text_x_frozen.view(1, n * L, dt).expand(R, -1, -1))
-        x0.view(R, n, L, dt)[:, :, 1:1 + nc] = (self.c_shift[:R] + self.text_pos[1:1 + nc]).unsqueeze(1)
+        if self.coop_position == "end" and not self.coop_csc:
+            x0.view(R, n * L, dt).copy_(self.text_x_frozen.view(1, n * L, dt).expand(R, -1, -1))
+            x0.view(R, n, L, dt)[:, :, 1:1 + nc] = (self.c_shift[:R] + self.text_pos[1:1 + nc]).unsqueeze(1)
+        else:
+            # prompts = cat([prefix, ctx / class name in the configured order, suffix]) (trainers/coop.py:117-183), then
+            # + positional_embedding by position (TextEncoder.forward, :48)
+            tokpos = torch.index_select(self.text_tok, 0, self.c_src_rows).view(n, L, dt) + self.text_pos
+            x0.view(R, n * L, dt).copy_(tokpos.view(1, n * L, dt).expand(R, -1, -1))
+            cpos = self.text_pos.index_select(0, self.c_ctx_pos)                                  # [n * nc, dt]
+            cs = self.c_shift[:R]
+            vals = (cs if self.coop_csc else cs.unsqueeze(1).expand(R, n, nc, dt).reshape(R, n * nc, dt)) + cpos
+            for r in range(R):
+                x0[r * n * L:(r + 1) * n * L].index_copy_(0, self.c_ctx_rows_idx, vals[r])
         ch, catt, cg, ln = self.ch[:Rf], self.catt[:Rf], self.cg[:Rf], self.c_len[:nv]
         for l, blk in enumerate(self.txt):
             x, xm, qkv = self.cx[l][:Rf], self.cxm[l][:Rf], self.cqkv[l][:Rf]
@@ -936,7 +991,14 @@ class Engine:
             ops.gemm_nt(dq, self.c_w_in_t[l], dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)
             ops.layernorm_bwd(dy[:SPLIT_Q], self.cx[l][:Rf], blk.ln1_w, dxb, dxa, None if f32m else dxc)
         rows = self.c_ctx_rows[:nv * nc]
-        rows.view(nv, nc, dt).copy_(dxa.view(nv, L, dt)[:, 1:1 + nc])
+        if self.coop_position == "end" and not self.coop_csc:
+            rows.view(nv, nc, dt).copy_(dxa.view(nv, L, dt)[:, 1:1 + nc])
+        else:
+            for r in range(R):          # the rows the context vectors sat in, class-major
+                torch.index_select(dxa[r * n * L:(r + 1) * n * L], 0, self.c_ctx_rows_idx, out=rows[r * n * nc:(r + 1) * n * nc])
+        if self.coop_csc:               # every class has its own vectors: nothing to sum
+            self.c_dshift[0].copy_(rows[:n * nc])
+            return
         for r in range(R):              # reduce_groups sums `groups` consecutive blocks of `rows` rows: the classes
             ops.reduce_groups(rows[r * n * nc:(r + 1) * n * nc], self.c_dshift[r], n)
 
@@ -959,7 +1021,7 @@ class Engine:
         cfg = self.cfg
         e, n = cfg.embed, cfg.n_cls
         train = label is not None
-        self.c_shift[0].copy_(self.coop_ctx)
+        self.c_shift[0].copy_(self.coop_ctx.view(-1, cfg.d_t))
         # the two towers are independent until the head: the (small, latency-bound) dense text forward runs on the side
         # stream under the image tower, as RPO's text chain does (RPO_COOP_SERIAL=1: one stream)
         if os.environ.get("RPO_COOP_SERIAL") == "1":
@@ -979,7 +1041,7 @@ class Engine:
                          self.c_d_text_f[:n].view(n, 1, e) if train else None, self.head_ws, **extra)
         if train:
             self._coop_text_backward()
-            self.coop_grad.copy_(self.c_dshift[0])
+            self.coop_grad.view(-1, cfg.d_t).copy_(self.c_dshift[0])
         return self.logits[:B]
 
     def cocoop_forward_backward(self, image: torch.Tensor, label: Optional[torch.Tensor]) -> torch.Tensor:

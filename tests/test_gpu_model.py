@@ -818,6 +818,99 @@ def test_coop_context_training_matches_reference_trainer(tag, depth, B, n_ctx, m
     assert np.array_equal(eng.coop_grad.cpu().numpy(), g)
 
 
+@pytest.mark.parametrize("tag,depth,B,n_ctx", [("d2_b3_ctx4_csc", 2, 3, 4), ("d2_b2_ctx4_middle", 2, 2, 4),
+                                               ("d2_b2_ctx5_middle_csc", 2, 2, 5), ("d2_b2_ctx4_front", 2, 2, 4)])
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_coop_options_match_reference_trainer(tag, depth, B, n_ctx, mode):
+    """CoOp's non-default options on the HIP path -- class-specific contexts (TRAINER.COOP.CSC, trainers/coop.py:84-86:
+    ctx [n_cls, n_ctx, d], no sum over the classes in the backward) and CLASS_TOKEN_POSITION "middle" / "front"
+    (:136-183: the class-name tokens re-ordered around the context before the positional embedding is added) -- against
+    the reference's own coop.CustomCLIP + F.cross_entropy + backward with those options set."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoOpCustomCLIP
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_coop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[mode]
+    csc, pos = bool(gold["csc"]), str(gold["class_token_position"])
+    m = CoOpCustomCLIP(sd, gold["tokenized_prompts"], n_ctx, "cuda:0", dt, max_batch=4, ctx=gold["ctx"], csc=csc,
+                       class_token_position=pos)
+    image = torch.from_numpy(synth.images(cfg, B)).cuda()
+    label = torch.from_numpy(gold["label"]).cuda()
+    eng = m.engine
+    logits = eng.coop_forward_backward(image, label).cpu().numpy()
+    loss, g = eng.loss.item(), eng.coop_grad.cpu().numpy()
+    assert g.shape == gold["ctx_grad"].shape
+    le, ll, gr = np.abs(logits - gold["logits"]).max(), abs(loss - float(gold["loss"])), _relmax(g, gold["ctx_grad"])
+    print(f"[coop {tag} {mode}] logits err {le:.3e} loss err {ll:.3e} ctx_grad rel {gr:.3e}")
+    lt, gt = {"f32": (TOL_F32, TOL_F32), "f16": (F16_LOGIT_ATOL, F16_GRAD_REL), "bf16": (BF16_LOGIT_ATOL, BF16_GRAD_REL)}[mode]
+    assert le <= lt and ll <= lt and gr <= gt
+    assert np.array_equal(m(image).cpu().numpy(), logits)
+    eng.coop_forward_backward(image, label)
+    assert np.array_equal(eng.coop_grad.cpu().numpy(), g)
+
+
+def test_coop_checkpoints_amp_and_cocoop_test_batches(tmp_path):
+    """The rest of the sibling trainers' surface (advisor, round 3): Dassl-layout checkpoints written and read back
+    (trainers/coop.py:283-325 drops token_prefix / token_suffix), a class-specific-context trainer taking SGD steps, the
+    `amp` branch skipping a step with a non-finite gradient (:263-270), CTX_INIT word embeddings (:72-80), and CoCoOp
+    inference on a test batch larger than its training batch (the reference tests at batch 100 with a batch-1 model)."""
+    from rpo_amd.config import vit_b16
+    from rpo_amd.coop import CoCoOp, CoOp
+    from rpo_amd.trainer import OptimConfig
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_coop_d2_b3_ctx4_csc.npz")))
+    cfg = vit_b16(layers_v=2, layers_t=2, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    toks = gold["tokenized_prompts"]
+    oc = OptimConfig(lr=0.002, momentum=0.9, weight_decay=5e-4, warmup_epoch=0, lr_scheduler="constant")
+    tr = CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3, num_batches=2, ctx=gold["ctx"], csc=True, amp=True)
+    batch = {"img": torch.from_numpy(synth.images(cfg, 3)), "label": torch.from_numpy(gold["label"])}
+    out = tr.forward_backward(batch)
+    assert abs(out["loss"] - float(gold["loss"])) <= TOL_F32 and tr.skipped_steps == 0
+    ctx1 = tr.engine.coop_ctx.cpu().numpy().copy()
+    assert ctx1.shape == gold["ctx"].shape and np.abs(ctx1 - gold["ctx"]).max() > 0
+    # first SGD step: p -= lr * (g + wd * p)
+    np.testing.assert_allclose(ctx1, gold["ctx"] - oc.lr * (gold["ctx_grad"] + oc.weight_decay * gold["ctx"]), atol=2e-7)
+    fn = tr.save_model(str(tmp_path), is_best=True)
+    ck = torch.load(fn, weights_only=True)
+    assert set(ck["state_dict"]) == {"ctx", "token_prefix", "token_suffix"} and ck["state_dict"]["ctx"].shape == ctx1.shape
+    assert ck["state_dict"]["token_suffix"].shape == (cfg.n_cls, 77 - 1 - 4, cfg.d_t)
+    tr.forward_backward(batch)                                   # a second step, then back to the checkpoint
+    tr2 = CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3, num_batches=2, csc=True)
+    tr2.load_model(str(tmp_path))
+    assert np.array_equal(tr2.engine.coop_ctx.cpu().numpy(), ctx1)
+    assert torch.equal(tr2.engine.coop_moms.cpu(), ck["optimizer"]["state"][0]["momentum_buffer"].reshape(-1))
+    tr2.forward_backward(batch)
+    assert np.array_equal(tr2.engine.coop_ctx.cpu().numpy(), tr.engine.coop_ctx.cpu().numpy()), "resume != continue"
+    # amp: a non-finite gradient skips the step and is counted
+    before = tr.engine.coop_params.clone()
+    bad = {"img": batch["img"].clone(), "label": batch["label"]}
+    bad["img"][0, 0, 0, 0] = float("inf")
+    tr.forward_backward(bad)
+    assert tr.skipped_steps == 1 and torch.equal(tr.engine.coop_params, before)
+    # CTX_INIT: the embeddings of the initialisation words, given as token ids
+    ids = np.array([320, 1125, 539, 320])                        # "a photo of a"
+    tr3 = CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3, ctx_init=ids)
+    assert np.array_equal(tr3.engine.coop_ctx.cpu().numpy(), sd["token_embedding.weight"][ids])
+    # CoCoOp: test batch 5 on a model set up for training batch 2 -> chunks of 2, image by image the same logits
+    gc = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_cocoop_d2_b3_ctx4.npz")))
+    meta = {k: gc[k] for k in ("w1", "b1", "w2", "b2")}
+    co = CoCoOp(sd, gc["tokenized_prompts"], 4, oc, "cuda:0", torch.float32, batch_size=2, ctx=gc["ctx"], meta=meta)
+    imgs = torch.from_numpy(synth.images(cfg, 5, seed=91)).cuda()
+    co.model.prompt_learner.eval()
+    big = co.model_inference(imgs).cpu().numpy()
+    assert big.shape == (5, cfg.n_cls)
+    for b in range(5):
+        one = co.model_inference(imgs[b:b + 1]).cpu().numpy()
+        np.testing.assert_allclose(big[b:b + 1], one, atol=2e-5)
+    fn = co.save_model(str(tmp_path / "cocoop"), epoch=3)
+    ck = torch.load(fn, weights_only=True)
+    assert {"ctx", "meta_net.linear1.weight", "meta_net.linear2.bias", "token_prefix"} <= set(ck["state_dict"])
+    co2 = CoCoOp(sd, gc["tokenized_prompts"], 4, oc, "cuda:0", torch.float32, batch_size=2)
+    co2.load_model(str(tmp_path / "cocoop"), epoch=3)
+    assert torch.equal(co2.engine.coop_params, co.engine.coop_params) and co2.epoch == 3
+
+
 def test_coop_trainer_sgd_steps_match_oracle():
     """Three optimiser steps of the CoOp trainer (f32 mode) against the CPU oracle's autograd + torch-equivalent SGD on
     the same batches: ctx within 1e-3 (measured ~1e-7), losses within 1e-3; the oracle itself is pinned to the

@@ -153,6 +153,34 @@ def test_coop_oracle_matches_reference_trainer(tag, depth, B, n_ctx):
     assert np.abs(g.numpy() - gold["ctx_grad"]).max() <= 2e-5 * np.abs(gold["ctx_grad"]).max()
 
 
+@pytest.mark.parametrize("tag,depth,B,n_ctx", [("d2_b3_ctx4_csc", 2, 3, 4), ("d2_b2_ctx4_middle", 2, 2, 4),
+                                               ("d2_b2_ctx5_middle_csc", 2, 2, 5), ("d2_b2_ctx4_front", 2, 2, 4)])
+def test_coop_oracle_options_match_reference_trainer(tag, depth, B, n_ctx):
+    """The reference's non-default CoOp options -- class-specific contexts (trainers/coop.py:84-86), class token in the
+    "middle" / at the "front" (:136-183) -- of the oracle against the reference's own CustomCLIP + cross_entropy +
+    backward with those options set (fixtures carry `csc`, `class_token_position`, and the tokenizer's `name_lens`,
+    which the oracle must recover from the token ids alone)."""
+    import os
+    import torch
+    from oracle.rpo_oracle import coop_loss_and_grad
+    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_coop_{tag}.npz")))
+    cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
+    sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
+    assert gold["weights_crc"].item().decode() == synth.state_dict_checksum(sd)
+    csc, pos = bool(gold["csc"]), str(gold["class_token_position"])
+    assert gold["ctx"].shape == ((cfg.n_cls, n_ctx, cfg.d_t) if csc else (n_ctx, cfg.d_t))
+    toks = gold["tokenized_prompts"]
+    assert np.array_equal(toks.argmax(-1) - n_ctx - 2, gold["name_lens"])      # name_len from the ids = the tokenizer's
+    logits, loss, g = coop_loss_and_grad(sd, synth.images(cfg, B), toks, gold["ctx"], gold["label"], cfg.patch,
+                                         class_token_position=pos)
+    assert np.abs(logits.numpy() - gold["logits"]).max() <= 3e-5
+    assert abs(float(loss) - float(gold["loss"])) <= 1e-5
+    assert np.abs(g.numpy() - gold["ctx_grad"]).max() <= 2e-5 * np.abs(gold["ctx_grad"]).max()
+    if pos != "end":                                                          # the position matters: "end" gives other logits
+        other, _, _ = coop_loss_and_grad(sd, synth.images(cfg, B), toks, gold["ctx"], gold["label"], cfg.patch)
+        assert np.abs(other.numpy() - gold["logits"]).max() > 1e-3
+
+
 @pytest.mark.parametrize("tag,depth,B", [("d2_b1_ctx4", 2, 1), ("d2_b3_ctx4", 2, 3)])
 def test_cocoop_oracle_matches_reference_trainer(tag, depth, B):
     """oracle.rpo_oracle.cocoop_loss_and_grads against the reference's own cocoop.CustomCLIP + backward

@@ -14,7 +14,10 @@ from rpo_amd.config import vit_b16                # noqa: E402
 
 ref_clip, CLIP, _ = _reference()
 toks = synth.oxford_pets_base_tokens()
+only = [a for a in sys.argv[1:] if not a.startswith("-")]       # fixture tags to (re)generate; none: all of them
 for tag, depth, B in (("d2_b3", 2, 3), ("d12_b2", 12, 2)):
+    if only and tag not in only:
+        continue
     cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
     sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
     model = CLIP(cfg.embed, cfg.image_size, cfg.layers_v, cfg.d_v, cfg.patch, cfg.context, cfg.vocab, cfg.d_t,
@@ -41,18 +44,26 @@ import trainers.coop as ref_coop                  # noqa: E402  (same stubs as t
 from rpo_amd.config import OXFORD_PETS_BASE_CLASSES  # noqa: E402
 
 ns = types.SimpleNamespace
-for tag, depth, B, n_ctx in (("d2_b3_ctx4", 2, 3, 4), ("d2_b2_ctx16", 2, 2, 16)):
+# (tag, depth, batch, n_ctx, CSC, CLASS_TOKEN_POSITION): the defaults, then the reference's other options (round 4)
+CASES = (("d2_b3_ctx4", 2, 3, 4, False, "end"), ("d2_b2_ctx16", 2, 2, 16, False, "end"),
+         ("d2_b3_ctx4_csc", 2, 3, 4, True, "end"), ("d2_b2_ctx4_middle", 2, 2, 4, False, "middle"),
+         ("d2_b2_ctx5_middle_csc", 2, 2, 5, True, "middle"), ("d2_b2_ctx4_front", 2, 2, 4, False, "front"))
+for tag, depth, B, n_ctx, csc, position in CASES:
+    if only and tag not in only:
+        continue
     cfg = vit_b16(layers_v=depth, layers_t=depth, K=1)
     sd = synth.clip_state_dict(cfg, seed=0, logit_scale=float(np.log(100.0)))
     clip_model = CLIP(cfg.embed, cfg.image_size, cfg.layers_v, cfg.d_v, cfg.patch, cfg.context, cfg.vocab, cfg.d_t,
                       cfg.heads_t, cfg.layers_t).float()
     clip_model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
-    rcfg = ns(TRAINER=ns(COOP=ns(N_CTX=n_ctx, CTX_INIT="", CSC=False, CLASS_TOKEN_POSITION="end", PREC="fp32")),
+    rcfg = ns(TRAINER=ns(COOP=ns(N_CTX=n_ctx, CTX_INIT="", CSC=csc, CLASS_TOKEN_POSITION=position, PREC="fp32")),
               INPUT=ns(SIZE=(cfg.image_size, cfg.image_size)))
     model = ref_coop.CustomCLIP(rcfg, list(OXFORD_PETS_BASE_CLASSES), clip_model)
     for name, p in model.named_parameters():
         p.requires_grad_("prompt_learner" in name)             # trainers/coop.py:228-230
-    ctx = (np.random.default_rng(11).standard_normal((n_ctx, cfg.d_t)) * 0.02).astype(np.float32)
+    shape = (len(OXFORD_PETS_BASE_CLASSES), n_ctx, cfg.d_t) if csc else (n_ctx, cfg.d_t)
+    ctx = (np.random.default_rng(11).standard_normal(shape) * 0.02).astype(np.float32)
+    assert tuple(model.prompt_learner.ctx.shape) == shape
     model.prompt_learner.ctx.data = torch.from_numpy(ctx.copy())
     image = torch.from_numpy(synth.images(cfg, B))
     label = torch.from_numpy(synth.labels(cfg, B))
@@ -63,6 +74,8 @@ for tag, depth, B, n_ctx in (("d2_b3_ctx4", 2, 3, 4), ("d2_b2_ctx16", 2, 2, 16))
     np.savez_compressed(path, logits=logits.detach().numpy(), loss=np.float32(loss.item()), ctx=ctx,
                         ctx_grad=model.prompt_learner.ctx.grad.numpy(), label=label.numpy(),
                         tokenized_prompts=model.tokenized_prompts.numpy().astype(np.int64),
+                        name_lens=np.asarray(model.prompt_learner.name_lens, dtype=np.int64),
+                        csc=np.bool_(csc), class_token_position=np.str_(position),
                         weights_crc=np.bytes_(synth.state_dict_checksum(sd)))
     print("coop", tag, "loss", float(loss), "|ctx_grad|max", float(model.prompt_learner.ctx.grad.abs().max()),
           os.path.getsize(path), "bytes")
