@@ -307,22 +307,37 @@ template <typename T, int NT, bool TWO_PASS = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, int64_t ld, T* out,
                                                        int64_t ldo, int B, int H, int N, int Kp, float scale,
-                                                       int q_first) {
+                                                       int q_first, int split_from) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = AL<T, NT>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   // Block bid runs on XCD bid % 8: every XCD takes a contiguous run of (image, head) pairs, i.e. whole images -- the
   // images whose rows the out-proj / c_fc / c_proj kernels around this one handle on the same XCD (row units).
+  // split_from (round 4): the first `split_from` workgroups take one (image, head) unit each, the rest take HALF the query
+  // tiles of a unit (two workgroups per unit, each staging K / V itself) -- the launcher splits just enough units for
+  // the grid to fill both resident slots of every CU (B = 32: 256 whole + 2 x 128 halves = 512 workgroups), so that no
+  // CU hosts two whole units while another hosts one.
+  int unit, qpart = -1;
+  {
+    const int bid = blockIdx.x;
 #ifdef RPO_ATTN_PLAIN_ORDER
-  const int wgid = blockIdx.x;
+    unit = bid;
 #else
-  const int wgid = [&] {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  }();
+    auto remap = [&](int i, int n) {
+      const int qd = n >> 3, rm = n & 7, xcd = i & 7;
+      return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (i >> 3);
+    };
+    if (bid < split_from) {
+      unit = remap(bid, split_from);
+    } else {
+      const int j = remap(bid - split_from, (int)gridDim.x - split_from);
+      unit = split_from + (j >> 1);
+      qpart = j & 1;
+    }
 #endif
+  }
+  const int wgid = unit;
   const int b = wgid / H, h = wgid % H;
   const T* kb = k + (int64_t)b * N * ld + h * 64;
   const T* vb = v + (int64_t)b * N * ld + h * 64;
@@ -339,7 +354,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   RowFrag<T> qf;
   // q_first > 0: only queries q_first .. S-1 of every image are wanted (last block: the prompt rows); whole
   // 32-query tiles are skipped, the leading queries of the first computed tile are computed but not stored
-  const int qt0 = q_first >> 5;
+  int qt0 = q_first >> 5, qt_end = (S + 31) >> 5;
+  if (qpart >= 0) {                                // this workgroup's half of the query tiles
+    const int mid = qt0 + ((qt_end - qt0 + 1) >> 1);
+    if (qpart == 0) qt_end = mid; else qt0 = mid;
+  }
   if constexpr (sizeof(T) == 2) qf.load(q + qrow(qt0 + wave) * ld + h * 64, half);   // (f32: 32 live VGPRs too many)
   if constexpr (sizeof(T) == 2) {
     bf16x8_t vrows[(NT + 7) / 8][4];
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   __syncthreads();
   RPO_STAMP(3);
 
-  for (int qt = qt0 + wave; qt * 32 < S; qt += 8) {
+  for (int qt = qt0 + wave; qt < qt_end; qt += 8) {
     // K/V fragments in LDS do not depend on the query tile; without this opaque copy the
     // compiler hoists all of their ds_reads out of the loop and spills them to scratch
     int l31v = l31;
@@ -988,9 +1007,19 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
 #endif
   constexpr int bytes = AL<T, NT>::FWD_BYTES;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), bytes, &lds_ok)) return rc;
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), bytes, s, static_cast<const T*>(q),
+  // Two workgroups fit a CU.  EXPERIMENT (round 4, off: -DRPO_ATTN_SPLIT): with more units than CUs but fewer than
+  // slots, split units until the slots are full.  Measured same-box: the kernel's in-stream time drops 14.5 -> 12.5 us
+  // (B = 32: no CU hosts two whole units any more), but the STEP is 0.5 % slower (2.958 vs 2.943 ms, three alternating
+  // pairs) and the forward pair with the text tower beside it unchanged: a grid that fills every resident slot has no
+  // room left for the side queue's workgroups, whose hosts then run a third half-unit (profiles/r04_ab_attn_fwd_variants.txt).
+  const int units = B * H, cus = rpo_cu_count();
+  int nsplit = 0;
+#ifdef RPO_ATTN_SPLIT
+  if (sizeof(T) == 2 && q_first == 0 && units > cus && units < 2 * cus) nsplit = 2 * cus - units < units ? 2 * cus - units : units;
+#endif
+  hipLaunchKernelGGL(kern, dim3(units + nsplit), dim3(512), bytes, s, static_cast<const T*>(q),
                      static_cast<const T*>(k), static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H,
-                     N, Kp, scale, q_first);
+                     N, Kp, scale, q_first, units - nsplit);
   return rpo_launch_status();
 }
 

@@ -636,6 +636,30 @@ def test_attn_readonly_fwd(mode, B, H, N, Kp):
     close(out, ref, mode, f"attn fwd B{B} H{H} N{N} K{Kp}")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,N,Kp", [(32, 12, 197, 24), (24, 12, 197, 4), (20, 16, 257, 24)])
+def test_attn_readonly_fwd_split_units_change_nothing(mode, B, H, N, Kp):
+    """A query's arithmetic does not depend on which workgroup computes it or on how many units a launch holds: the
+    whole-batch launch must give the bits of image-by-image launches.  (Also the check of the -DRPO_ATTN_SPLIT build,
+    which splits some units' query tiles over two workgroups when there are more units than CUs: attn_image.hip.)"""
+    o = ops()
+    d = 64 * H
+    qkv = _img_rows(B, N, Kp, d, 21)
+    t = qkv.to(dev(), DT[mode])
+    Rf, S = B * N, N + Kp
+    out = torch.full((B * S, d), float("nan"), dtype=DT[mode], device=dev())
+    o.attn_readonly_fwd(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], out, B, H, N, Kp)
+    assert not torch.isnan(out.float()).any()
+    for b in range(0, B, 5):
+        one = torch.cat([t[b * N:(b + 1) * N], t[Rf + b * Kp:Rf + (b + 1) * Kp]]).contiguous()
+        o1 = torch.full((S, d), float("nan"), dtype=DT[mode], device=dev())
+        o.attn_readonly_fwd(one[:, :d], one[:, d:2 * d], one[:, 2 * d:], o1, 1, H, N, Kp)
+        assert torch.equal(o1[:N], out[b * N:(b + 1) * N]) and torch.equal(o1[N:], out[Rf + b * Kp:Rf + (b + 1) * Kp]), b
+    again = torch.empty_like(out)
+    o.attn_readonly_fwd(t[:, :d], t[:, d:2 * d], t[:, 2 * d:], again, B, H, N, Kp)
+    assert torch.equal(again, out)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,H,N,Kp", [(2, 3, 197, 24), (1, 2, 50, 7), (2, 1, 257, 48), (1, 1, 197, 33)])
 def test_attn_readonly_bwd(mode, B, H, N, Kp):
