@@ -303,7 +303,8 @@ def test_gemm_row_unit_hint_changes_tiling_not_results(mode, n0, n1, units, N):
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
 @pytest.mark.parametrize("n0,n1,units,K", [(197, 24, 32, 768), (197, 24, 32, 3072), (197, 4, 32, 256), (190, 34, 30, 512),
-                                           (224, 0, 28, 1024), (197, 24, 64, 256)])   # 64 units: two rounds
+                                           (224, 0, 28, 1024), (197, 24, 64, 256),    # 64 units: two rounds
+                                           (197, 48, 32, 768), (197, 48, 32, 3072), (230, 26, 30, 256)])   # 256x96 tiles (K = 48)
 def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
     """The 224x96 kernel of the N = 768 residual GEMMs (tile_config 11; out-proj / c_proj of the image tower: one row
     unit x 96 columns per workgroup, the four waves split the contraction): C, the 16-bit copy and the 96-column row
@@ -375,7 +376,8 @@ def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
-@pytest.mark.parametrize("n0,n1,units,N,K", [(197, 24, 32, 768, 768), (197, 24, 32, 768, 3072), (257, 24, 16, 1024, 1024)])
+@pytest.mark.parametrize("n0,n1,units,N,K", [(197, 24, 32, 768, 768), (197, 24, 32, 768, 3072), (257, 24, 16, 1024, 1024),
+                                             (197, 48, 32, 768, 768), (197, 48, 32, 768, 3072)])      # 256x96 tiles (K = 48)
 def test_gemm_residual_stream_as_hi_lo_halves(mode, n0, n1, units, N, K):
     """rpo_gemm_args.resid_hi / resid_lo / out_lo / c_row0: the residual stream of the one-round residual GEMMs as two
     16-bit halves.  With a residual that IS exactly hi + lo the result must equal the fp32-residual launch bit for bit

@@ -7,6 +7,7 @@ of the 64 k's) of every 64-deep k-tile; TM x TN accumulators of 16 registers (op
 tuples), reduced across the waves by the epilogue.  Two geometries:
   W4K_LOOP      tile 224 (7 x 32) x 96 (3 x 32), LDS ring of 4 slots -- ViT-B/16 (197 + K <= 224 rows, 768 = 8 x 96)
   W4K_LOOP_9X2  tile 288 (9 x 32) x 64 (2 x 32), LDS ring of 3 slots -- ViT-L/14 (257 + K <= 288 rows, 1024 = 16 x 64)
+  W4K_LOOP_8X3  tile 256 (8 x 32) x 96 (3 x 32), LDS ring of 3 slots -- ViT-B/16 with 225 .. 256 rows per image (K = 48)
 LDS: ring of R slots x (BM + BN) rows x 128 B.  Iteration t: wait for the wave's own fragment reads of tile t (issued
 during iteration t-1) and its own DMA pieces of tile t+1, barrier -- now every wave holds tile t in registers and tile
 t+1 is complete in LDS, so slot t % R is dead -- then the MFMAs on the fragments of tile t (set t % 2), the fragment
@@ -170,7 +171,7 @@ def main():
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_w4k.py -- do not edit; the schedule and its wait counts are derived there.\n")
         f.write("// W4K_OP (the MFMA mnemonic) is bound where W4K_LOOP is expanded.\n")
-        for geo in (Geo(7, 3, 4, [0], ""), Geo(9, 2, 3, [3, 5], "_9X2")):
+        for geo in (Geo(7, 3, 4, [0], ""), Geo(9, 2, 3, [3, 5], "_9X2"), Geo(8, 3, 3, [3, 5], "_8X3")):
             G = geo
             L = loop_lines()
             f.write(f"#define W4K_LOOP{geo.suffix} \\\n")
