@@ -29,6 +29,10 @@ timeout 200 python bench.py --dtype f32 --steps 20 --warmup 5 $B > $O/bench_f32.
 timeout 200 python bench.py --dtype f16 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_f16.json 2>> $O/bench.err
 timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench_eval.json 2>> $O/bench.err
 [ -z "${QUICK:-}" ] && timeout 200 python bench.py --steps 20 --warmup 5 --input-pipeline $B > $O/bench_input_pipeline.json 2>> $O/bench.err
+# the sibling trainers at the reference's own defaults (CoOp: batch 32, n_ctx 16; CoCoOp: batch 1, n_ctx 4), graph-captured steps
+timeout 300 python bench.py --trainer coop --steps 30 --warmup 5 --no-precision > $O/bench_coop.json 2>> $O/bench.err
+timeout 300 python bench.py --trainer cocoop --steps 30 --warmup 5 --no-precision > $O/bench_cocoop.json 2>> $O/bench.err
+timeout 200 python tools/attn_timeline.py 8 16 32 2>&1 | grep -v amdgpu.ids > $O/attn_timeline.txt
 timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
 timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
 [ -z "${QUICK:-}" ] && timeout 300 python tools/probe_cu_mask.py 2>&1 | grep -v amdgpu.ids > $O/cu_mask_probe.txt
