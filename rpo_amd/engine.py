@@ -182,6 +182,12 @@ class Engine:
         Lv, Lt = cfg.layers_v, cfg.layers_t
         self.im2col = a(B * cfg.n_patches, self.kpatch)
         self.x_pre = f32(R, dv)
+        # Residual stream at the layer boundaries, fp32.  INVARIANT of the hi / lo mode (16-bit modes at batch sizes with a
+        # one-round geometry, the default there): after a forward pass only the PROMPT rows [B*N, B*(N+K)) of x[l] (l >= 1)
+        # and xm[l] hold this pass's values -- the stream of all rows lives in h (hi) + h_lo, updated in place, and the
+        # frozen rows of these tensors keep whatever an earlier call left (advisor, round 3).  Nothing in-tree reads them
+        # outside forward_plain / the sibling trainers (full_last: fp32 for every row); a tool that inspects frozen rows
+        # must run with RPO_NO_HILO=1 (tools/probe_alias_buffers.py does).
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
         self.h = a(R, dv)

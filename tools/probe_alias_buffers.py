@@ -3,6 +3,7 @@
 (two ping-pong x buffers, one xm buffer) instead of one buffer per layer?  (Results are wrong for the backward -- the
 per-layer buffers exist because the backward reads the prompt rows of every layer -- this only times the forward.)"""
 import os, sys, time
+os.environ.setdefault("RPO_NO_HILO", "1")   # this probe reads frozen rows of Engine.x / xm (see the invariant there)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rpo_amd import synth
