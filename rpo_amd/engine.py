@@ -496,9 +496,10 @@ class Engine:
     def _split_rows(self, B: int) -> bool:
         """Whether the image forward runs its frozen rows and its prompt rows as separate launches (see _image_forward):
         16-bit modes with the LayerNorm fold, when the one-round row-unit kernels take an image's N frozen rows but not
-        its N + K rows."""
+        its N + K rows (RPO_SPLIT=1), or wherever they take the frozen rows (RPO_SPLIT=force: the test's switch)."""
         cfg = self.cfg
-        if self.act == torch.float32 or not self.fold_ln or os.environ.get("RPO_SPLIT") != "1" or cfg.K == 0:
+        mode = os.environ.get("RPO_SPLIT", "0")          # "1": where the whole rows do not fit; "force": wherever the frozen rows do
+        if self.act == torch.float32 or not self.fold_ln or mode not in ("1", "force") or cfg.K == 0:
             return False
         key = ("split", B)
         if key not in self._stats_group:
@@ -506,7 +507,8 @@ class Engine:
             Rf, R = B * N, B * (N + K)
             whole = ops.gemm_hilo_ok(R, dv, dv, self.act, (N, K, Rf), ops.gemm_stats_group(R, dv, dv, self.act, (N, K, Rf)))
             frozen = ops.gemm_hilo_ok(Rf, dv, dv, self.act, (N, 0, Rf), ops.gemm_stats_group(Rf, dv, dv, self.act, (N, 0, Rf)))
-            self._stats_group[key] = bool(frozen and not whole)
+            # (round 4: with the 256x96 geometry K = 48 -- 245 rows -- fits whole; "1" now engages from 257 rows on)
+            self._stats_group[key] = bool(frozen and (mode == "force" or not whole))
         return self._stats_group[key]
 
     # ------------------------------------------------------------------ backward pieces
