@@ -408,7 +408,7 @@ def test_generated_k_loops_are_what_the_generators_emit(tmp_path):
 
 def test_stats_group_query_needs_no_gpu():
     """rpo_gemm_stats_group is pure host logic (which partial-statistics layout a BIAS_RESID producer writes): 96 where the
-    224x96 kernel applies (ViT-B/16, 32 / 64 images, K <= 27 prompts), 64 for the 288x64 geometry (ViT-L/14, 16 images) and
+    224x96 / 256x96 kernel applies (ViT-B/16, 32 / 64 images, K <= 59 prompts), 64 for the 288x64 geometry (ViT-L/14, 16 images) and
     wherever the generic tiles run."""
     import torch
     from rpo_amd import ops
@@ -418,7 +418,8 @@ def test_stats_group_query_needs_no_gpu():
     assert g(2 * 7072, 768, 3072, torch.bfloat16, (197, 24, 2 * 6304)) == 96          # two rounds
     assert g(7072, 768, 768, torch.bfloat16, None) == 64                               # no row units
     assert g(7072, 768, 768, torch.float32, (197, 24, 6304)) == 64                     # f32 mode: generic kernels
-    assert g(32 * 245, 768, 768, torch.bfloat16, (197, 48, 32 * 197)) == 64            # K = 48: 245 rows per image
+    assert g(32 * 245, 768, 768, torch.bfloat16, (197, 48, 32 * 197)) == 96            # K = 48: 245 rows per image -> 256x96 tiles (round 4)
+    assert g(32 * 261, 768, 768, torch.bfloat16, (197, 64, 32 * 197)) == 64            # K = 64: 261 rows: no one-round geometry
     assert g(3536, 768, 768, torch.bfloat16, (197, 24, 3152)) == 64                    # 16 images: half a round
     assert g(16 * 281, 1024, 4096, torch.bfloat16, (257, 24, 16 * 257)) == 64          # ViT-L/14: 288x64 tiles
     assert g(7072, 768, 192, torch.bfloat16, (197, 24, 6304)) == 64                    # K = 192: 3 k-tiles, not admitted
