@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 5
+#define RPO_ABI_VERSION 6
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -190,6 +190,18 @@ int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x
  * epilogue (NONE or QGELU_BWD) and split_k, M < 2048, tile_config 0, no skip_*; otherwise RPO_E_SHAPE / RPO_E_DTYPE and
  * nothing is launched.  Bit-identical to two rpo_gemm_nt calls. */
 int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1, void* stream);
+
+/* ---- c_fc -> c_proj of an image block as ONE launch (ABI 6; experiment of round 4, off by default in the engine) --------
+ * `fc` / `proj` are the arguments of the two rpo_gemm_nt calls it stands for: x += c_proj(QuickGELU(c_fc(ln_2 x))),
+ * clip/model.py:173-177,190 -- fc with a BIAS_QGELU / LN_BIAS_QGELU epilogue, proj with BIAS_RESID and proj->A == fc->C.
+ * Applies (else RPO_E_SHAPE: issue the two calls) when both run on the one-round row-unit kernels with the same row units
+ * and every workgroup is resident at once (units * 8 <= CUs): a workgroup then runs its c_fc tile, waits for the 7 other
+ * workgroups of its row unit at `counters[unit]`, and runs its c_proj tile.  `counters`: units + 1 uint32, zeroed
+ * ONCE by the caller (never reset: the kernel counts in rounds of 8; the last word counts polls that gave up after
+ * ~10 s -- it must stay 0).  `safe` = 0 relies on the 8 workgroups of a unit
+ * sharing an XCD's L2 (what the dispatch order gives today); `safe` = 1 adds an agent-scope release / acquire around the
+ * hand-off and is placement-independent.  Results are those of the two launches, bit for bit. */
+int rpo_mlp_fused(const rpo_gemm_args* fc, const rpo_gemm_args* proj, void* counters, int safe, void* stream);
 
 /* rpo_layernorm_bwd for two problems in one launch (fp32 dy slabs; both casts, where present, of one dtype). */
 typedef struct rpo_ln_bwd_args {

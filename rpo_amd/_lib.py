@@ -103,6 +103,7 @@ SIGNATURES = {
     "rpo_error_string": (C.c_char_p, [c_i32]),
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
+    "rpo_mlp_fused": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp, c_i32, c_vp]),
     "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),
     "rpo_attn_bwd_proj_pair": (c_i32, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_i32, c_vp]),
     "rpo_chain_state_bytes": (C.c_size_t, []),

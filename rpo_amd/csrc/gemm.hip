@@ -902,6 +902,7 @@ __global__ __launch_bounds__(CfgPP::THREADS) void gemm_pp_kernel(const GemmParam
 #include "gemm_w4.inc"
 #include "gemm_w4g.inc"
 #include "gemm_w4k.inc"
+#include "gemm_mlp.inc"
 
 template <typename TOut, int EPI>
 int launch_pp(const GemmParams& p, hipStream_t s) {
@@ -1159,6 +1160,41 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
     return dispatch_f32out<bf16_t>(epi, p, s);
   }
   return dispatch_f32out<float>(epi, p, s);
+}
+
+// c_fc -> c_proj of an image block in ONE launch (gemm_mlp.inc; include/rpo_amd.h).  RPO_E_SHAPE where it does not apply
+// (the caller then issues the two rpo_gemm_nt calls it stands for): both GEMMs must be the row-unit, one-round forms --
+// 224x384 tiles with a QuickGELU epilogue feeding 224x96 split-k tiles with the residual epilogue, the same row units, 8
+// column tiles each, every workgroup resident at once.
+extern "C" int rpo_mlp_fused(const rpo_gemm_args* fc, const rpo_gemm_args* proj, void* counters, int safe, void* stream) {
+  GemmParams pf, pp;
+  if (counters == nullptr) return RPO_E_BADARG;
+  if (int rc = gemm_prepare(fc, pf)) return rc;
+  if (int rc = gemm_prepare(proj, pp)) return rc;
+  const bool in16 = fc->in_dtype == RPO_BF16 || fc->in_dtype == RPO_F16;
+  if (!in16 || fc->in_dtype != proj->in_dtype || fc->out_dtype != fc->in_dtype || proj->out_dtype != RPO_F32) return RPO_E_DTYPE;
+  if ((fc->epilogue != RPO_EPI_LN_BIAS_QGELU && fc->epilogue != RPO_EPI_BIAS_QGELU) || proj->epilogue != RPO_EPI_BIAS_RESID)
+    return RPO_E_SHAPE;
+  if (pf.split_k != 1 || pp.split_k != 1 || pf.force_cfg != 0 || pp.force_cfg != 0 || pf.M != pp.M || pp.K != pf.N ||
+      proj->A != fc->C || pp.lda != pf.ldc) return RPO_E_SHAPE;
+  W4GPlan g;
+  W4KPlan k;
+  const bool fits32 = (int64_t)pf.M * pf.lda * 2 < (1ll << 31) && (int64_t)pf.N * pf.ldw * 2 < (1ll << 31) &&
+                      (int64_t)pp.M * pp.lda * 2 < (1ll << 31) && (int64_t)pp.N * pp.ldw * 2 < (1ll << 31);
+  if (!fits32 || w4g_plan(pf, &g) != 1 || !g.from_units || w4k_plan(pp, &k) != CfgW4K::BN || k.geo != CfgW4K::TM) return RPO_E_SHAPE;
+  if (g.rows0 != k.rows0 || g.rows1 != k.rows1 || g.seg1_base != k.seg1_base || g.tiles_m != k.tiles_m || g.tiles_n != 8 ||
+      k.tiles_n != 8 || g.tiles_m * 8 > rpo_cu_count()) return RPO_E_SHAPE;
+  if (pf.K < 2 * CfgW4G::BK || pf.N % 8 != 0 || pf.ldc % 8 != 0 || !aligned16(pf.C) || !aligned16(pp.C) || pp.ldc % 4 != 0 ||
+      (pp.ln_stats != nullptr && pp.ln_group != CfgW4K::BN)) return RPO_E_SHAPE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned int* cnt = static_cast<unsigned int*>(counters);
+  const bool ln = fc->epilogue == RPO_EPI_LN_BIAS_QGELU;
+  if (ln && pf.K > 16 * pf.ln_group) return RPO_E_SHAPE;
+  if (fc->in_dtype == RPO_F16)
+    return ln ? launch_mlp_fused<f16_t, RPO_EPI_LN_BIAS_QGELU>(pf, pp, g, cnt, safe, s)
+              : launch_mlp_fused<f16_t, RPO_EPI_BIAS_QGELU>(pf, pp, g, cnt, safe, s);
+  return ln ? launch_mlp_fused<bf16_t, RPO_EPI_LN_BIAS_QGELU>(pf, pp, g, cnt, safe, s)
+            : launch_mlp_fused<bf16_t, RPO_EPI_BIAS_QGELU>(pf, pp, g, cnt, safe, s);
 }
 
 // Two GEMMs in one launch (see gemm_nt_pair_kernel): the same stage of the image tower's and of the text tower's

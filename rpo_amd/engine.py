@@ -190,6 +190,7 @@ class Engine:
         # must run with RPO_NO_HILO=1 (tools/probe_alias_buffers.py does).
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
+        self.mlp_counters = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # rpo_mlp_fused: one per row unit + give-ups, never reset
         self.h = a(R, dv)
         self.h_lo = a(R, dv)                         # lo half of the residual stream (hi / lo mode: _image_forward)
         self.ln_stats = f32(R, dv // 64, 2)          # per-row partial LayerNorm statistics of the tensor self.h copies
@@ -414,6 +415,8 @@ class Engine:
             return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
                     "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
         no_probe = lambda name: _NO_PROBE
+        mlp_fused = os.environ.get("RPO_MLP_FUSED", "0")
+        mlp_fused = mlp_fused if mlp_fused in ("1", "safe") and self.act != torch.float32 else ""
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
             # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
@@ -470,6 +473,23 @@ class Engine:
                 with timed("out_proj"):
                     ops.gemm_nt(att[lo:hi], blk.w_out, xm[lo:hi], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
                                 **res_o, **prod, prefetch=pf_of("out", l) if wide else None)
+                # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
+                prod_p = dict(out2=h[lo:hi], ln_stats=sp[lo:hi], ln_group=gp) if (fold and l < last) else {}
+                res_p = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if hl else dict(resid=xm[lo:hi])
+                if hl:
+                    prod_p.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)
+                proj_kw = dict(a=g[lo:hi], w=blk.w_proj, out=xo[lo:hi], epilogue=EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
+                               **res_p, **prod_p, prefetch=pf_of("proj", l) if wide else None)
+                # EXPERIMENT (round 4, RPO_MLP_FUSED=1 / =safe): c_fc -> c_proj of a whole-batch block as ONE launch
+                # (rpo_mlp_fused: the 8 workgroups of an image hand g over through their XCD's L2 at a counter)
+                if fold and wide and mlp_fused:
+                    fc_kw = dict(a=h[lo:hi], w=blk.w_fc_ln, out=g[lo:hi], epilogue=EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                                 aux=aux, aux_row0=aux_row0, ln_stats=so[lo:hi], ln_colsum=blk.s_fc, row_units=un,
+                                 ln_group=go, prefetch=pf_of("fc", l))
+                    with timed("c_fc"):
+                        done = ops.mlp_fused(fc_kw, proj_kw, self.mlp_counters, safe=(mlp_fused == "safe"))
+                    if done:
+                        continue
                 if fold:
                     with timed("c_fc"):
                         ops.gemm_nt(h[lo:hi], blk.w_fc_ln, g[lo:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
@@ -482,14 +502,8 @@ class Engine:
                     with timed("c_fc"):
                         ops.gemm_nt(h[lo:hi], blk.w_fc, g[lo:hi], EPI_BIAS_QGELU, bias=blk.b_fc,
                                     aux=aux, aux_row0=aux_row0, row_units=un)
-                # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
-                prod = dict(out2=h[lo:hi], ln_stats=sp[lo:hi], ln_group=gp) if (fold and l < last) else {}
-                res_p = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if hl else dict(resid=xm[lo:hi])
-                if hl:
-                    prod.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)
                 with timed("c_proj"):
-                    ops.gemm_nt(g[lo:hi], blk.w_proj, xo[lo:hi], EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
-                                **res_p, **prod, prefetch=pf_of("proj", l) if wide else None)
+                    ops.gemm_nt(**proj_kw)
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 

@@ -113,6 +113,19 @@ def gemm_nt_pair(g0: dict, g1: dict) -> None:
     check(_lib.load().rpo_gemm_nt_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_gemm_nt_pair")
 
 
+def mlp_fused(fc: dict, proj: dict, counters: torch.Tensor, safe: bool = False) -> bool:
+    """c_fc -> c_proj in ONE launch (rpo_mlp_fused): fc / proj are the keyword arguments of the two `gemm_nt` calls it
+    stands for (a, w, out, epilogue, ...).  Returns False where the kernel does not apply (RPO_E_SHAPE): the caller then
+    issues the two calls."""
+    a0, a1 = gemm_args(**fc), gemm_args(**proj)
+    assert counters.dtype == torch.int32 and counters.is_contiguous()
+    rc = _lib.load().rpo_mlp_fused(C.byref(a0), C.byref(a1), counters.data_ptr(), int(safe), _stream())
+    if rc == -2:                                     # RPO_E_SHAPE
+        return False
+    check(rc, "rpo_mlp_fused")
+    return True
+
+
 def gemm_stats_group(M: int, N: int, K: int, dtype: torch.dtype, row_units: Optional[tuple]) -> int:
     """Columns per partial row statistic a BIAS_RESID producer [M, K] x [N, K]^T -> fp32 writes (rpo_gemm_stats_group)."""
     if dtype == torch.float32:

@@ -1048,6 +1048,31 @@ def test_joint_backward_equals_the_two_chains(monkeypatch, B):
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("how", ["1", "safe"])
+def test_mlp_fused_step_equals_the_default_schedule(monkeypatch, how):
+    """RPO_MLP_FUSED=1 / =safe (opt-in, Engine._image_forward): c_fc -> c_proj of every whole-batch image block as one
+    launch (rpo_mlp_fused).  The same tile arithmetic, so loss and both gradients of a B = 32 step must be the BITS of
+    the default schedule's, and within the golden bounds of the reference."""
+    from rpo_amd.custom_clip import CustomCLIP
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_full_k24_b32.npz")))
+    cfg, sd, toks, tp, ip, image, label = _full_workload("ViT-B/16", 24, 32)
+    out = {}
+    for mode in ("0", how):
+        monkeypatch.setenv("RPO_MLP_FUSED", mode)
+        m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float16, max_batch=32, prompts=(tp, ip))
+        loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        out[mode] = (loss.item(), m.prompt_learner.img_prompt.grad.cpu().numpy().copy(),
+                     m.prompt_learner.text_prompt.grad.cpu().numpy().copy(), int(m.engine.mlp_counters[:-1].sum().item()))
+        assert int(m.engine.mlp_counters[-1].item()) == 0, "a hand-off poll gave up"
+        del m
+    assert out["0"][3] == 0 and out[how][3] == 32 * 8 * 11, "11 whole-batch blocks x 32 images x 8 arrivals"
+    assert out[how][0] == out["0"][0] and np.array_equal(out[how][1], out["0"][1]) and np.array_equal(out[how][2], out["0"][2])
+    assert abs(out[how][0] - float(g["loss"])) <= F16_LOGIT_ATOL
+    assert _relmax(out[how][1], g["g_img"]) <= F16_GRAD_REL and _relmax(out[how][2], g["g_text"]) <= F16_GRAD_REL
+
+
 def test_split_row_launches_match_reference_golden(monkeypatch):
     """RPO_SPLIT=1 (opt-in, Engine._split_rows): at K = 48 an image's 245 rows do not fit the one-round 224-row tiles, its
     197 frozen rows do -- they keep the row-unit kernels (units of 197 + 0 rows) and the prompt rows run as their own

@@ -54,7 +54,7 @@ def test_library_loads_and_probe_layouts():
     """The fragment layouts every MFMA kernel assumes, checked on the device with an
     ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
     o = ops()
-    assert o.version() == 5
+    assert o.version() == 6
     for which, kdim in ((0, 16), (1, 2)):
         g = torch.Generator().manual_seed(which)
         a = torch.randint(-4, 5, (32, kdim), generator=g).float()
@@ -373,6 +373,68 @@ def test_gemm_one_round_224x96_split_k(mode, n0, n1, units, K):
         close(outs[0], R.qgelu(pre), mode, "LN-folded c_fc from 96-column statistics", tol=1.5 * TOL[mode])
         for y in outs[1:]:
             assert torch.equal(y, outs[0])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("safe", [False, True])
+@pytest.mark.parametrize("n0,n1,units", [(197, 24, 32), (197, 4, 32), (190, 34, 30)])
+def test_mlp_fused_equals_the_two_launches(mode, safe, n0, n1, units):
+    """rpo_mlp_fused (round 4, experiment): c_fc (LN-folded, QuickGELU, saved derivative of the prompt rows) and c_proj
+    (residual as hi / lo halves, in place; 16-bit copy + 96-column statistics) of an image block in ONE launch -- the 8
+    workgroups of a row unit hand g over at a counter.  Every output must be the bits of the two rpo_gemm_nt launches,
+    with the XCD-local hand-off and with the placement-independent one, over repeated launches on the same counters
+    (they are never reset); shapes the kernel does not cover are refused, not approximated."""
+    from rpo_amd import _lib as L
+    o = ops()
+    d, Nf = 768, 3072
+    dt = DT[mode]
+    seg1 = n0 * units
+    M = seg1 + n1 * units
+    hint = (n0, n1, seg1)
+    x = (rnd((M, d), 1, 2.0) + 0.4)
+    hi = x.to(dt); lo = (x - hi.float()).to(dt)
+    xb = hi.to(dev())
+    grp = x.double().reshape(M, d // 96, 96)
+    stats = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1).float().to(dev())
+    w_fc, b_fc = rnd((Nf, d), 2, d ** -0.5).to(dev(), dt), rnd((Nf,), 3).to(dev())
+    s_fc = w_fc.double().sum(1).float()
+    w_pr, b_pr = rnd((d, Nf), 4, Nf ** -0.5).to(dev(), dt), rnd((d,), 5).to(dev())
+
+    def buffers():
+        return dict(g=torch.full((M, Nf), float("nan"), dtype=dt, device=dev()),
+                    aux=torch.full((M - seg1, Nf), float("nan"), dtype=dt, device=dev()),
+                    c=torch.full((M, d), float("nan"), device=dev()), h=hi.to(dev()).clone(), l=lo.to(dev()).clone(),
+                    st=torch.full((M, d // 96, 2), float("nan"), device=dev()))
+
+    def kws(b):
+        fc = dict(a=xb, w=w_fc, out=b["g"], epilogue=L.EPI_LN_BIAS_QGELU, bias=b_fc, aux=b["aux"], aux_row0=seg1,
+                  ln_stats=stats, ln_colsum=s_fc, row_units=hint, ln_group=96)
+        pr = dict(a=b["g"], w=w_pr, out=b["c"], epilogue=L.EPI_BIAS_RESID, bias=b_pr, row_units=hint, resid_hi=b["h"],
+                  resid_lo=b["l"], out2=b["h"], out_lo=b["l"], c_row0=seg1, ln_stats=b["st"], ln_group=96)
+        return fc, pr
+    ref = buffers()
+    fc, pr = kws(ref)
+    o.gemm_nt(**fc); o.gemm_nt(**pr)
+    cnt = torch.zeros(units + 1, dtype=torch.int32, device=dev())            # + the give-up word
+    applies = units * 8 <= torch.cuda.get_device_properties(0).multi_processor_count
+    for rep in range(4):
+        got = buffers()
+        fc, pr = kws(got)
+        done = o.mlp_fused(fc, pr, cnt, safe=safe)
+        assert done == applies
+        if not done:
+            return
+        torch.cuda.synchronize()
+        for k in ("g", "aux", "h", "l", "st"):
+            assert torch.equal(got[k], ref[k]), (k, rep)
+        assert torch.equal(got["c"][seg1:], ref["c"][seg1:]) and torch.isnan(got["c"][:seg1]).all()
+    assert cnt.cpu().tolist() == [32] * units + [0]            # 4 launches x 8 arrivals, never reset; no poll gave up
+    # not the row-unit forms: refused
+    fc, pr = kws(buffers())
+    fc2 = dict(fc, row_units=None); pr2 = dict(pr, row_units=None, resid_hi=None, resid_lo=None, out_lo=None, c_row0=0,
+                                               resid=torch.zeros(M, d, device=dev()), ln_group=64,
+                                               ln_stats=torch.empty(M, d // 64, 2, device=dev()))
+    assert o.mlp_fused(fc2, pr2, cnt) is False
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f16"])
