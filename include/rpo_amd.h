@@ -199,8 +199,9 @@ int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1, void* str
  * workgroups of its row unit at `counters[unit]`, and runs its c_proj tile.  `counters`: units + 1 uint32, zeroed
  * ONCE by the caller (never reset: the kernel counts in rounds of 8; the last word counts polls that gave up after
  * ~10 s -- it must stay 0).  `safe` = 0 relies on the 8 workgroups of a unit
- * sharing an XCD's L2 (what the dispatch order gives today); `safe` = 1 adds an agent-scope release / acquire around the
- * hand-off and is placement-independent.  Results are those of the two launches, bit for bit. */
+ * sharing an XCD's L2 (what the dispatch order gives today, and only when the unit count is a multiple of 8: otherwise
+ * the library switches to the safe form itself); `safe` = 1 adds an agent-scope release / acquire around the hand-off
+ * and is placement-independent.  Results are those of the two launches, bit for bit. */
 int rpo_mlp_fused(const rpo_gemm_args* fc, const rpo_gemm_args* proj, void* counters, int safe, void* stream);
 
 /* rpo_layernorm_bwd for two problems in one launch (fp32 dy slabs; both casts, where present, of one dtype). */

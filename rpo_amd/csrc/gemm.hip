@@ -1188,6 +1188,10 @@ extern "C" int rpo_mlp_fused(const rpo_gemm_args* fc, const rpo_gemm_args* proj,
       (pp.ln_stats != nullptr && pp.ln_group != CfgW4K::BN)) return RPO_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned int* cnt = static_cast<unsigned int*>(counters);
+  // the XCD-local hand-off needs every row unit's 8 workgroups inside one XCD's contiguous share of the grid (nwg / 8
+  // workgroups each): only when the unit count is a multiple of 8; otherwise units straddle two XCDs and the hand-off
+  // must be the agent-scope one (caught by test_mlp_fused_equals_the_two_launches at 30 units)
+  if (g.tiles_m % 8 != 0) safe = 1;
   const bool ln = fc->epilogue == RPO_EPI_LN_BIAS_QGELU;
   if (ln && pf.K > 16 * pf.ln_group) return RPO_E_SHAPE;
   if (fc->in_dtype == RPO_F16)
