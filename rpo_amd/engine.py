@@ -626,6 +626,8 @@ class Engine:
             return False
         cfg = self.cfg
         if tower == "v":
+            if os.environ.get("RPO_CHAIN_IMAGE", "1") == "0":     # (text tower alone: RPO_CHAIN=1 RPO_CHAIN_TEXT=1 RPO_CHAIN_IMAGE=0)
+                return False
             return ops.chain_bwd_ok(cfg.layers_v, units, cfg.K, cfg.d_v, cfg.heads_v, cfg.n_frozen, self.act)
         if os.environ.get("RPO_CHAIN_TEXT", "0") != "1" or self.Lmax > 96:
             return False
