@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 6
+#define RPO_ABI_VERSION 7
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -155,6 +155,25 @@ const char* rpo_error_string(int code);
  * nn.MultiheadAttention's packed in-proj and out-proj (clip/model.py:171-177,186) and,
  * in the backward, autograd's mm(dY, W) (trainers/rpo.py:308). */
 int rpo_gemm_nt(const rpo_gemm_args* args, void* stream);
+
+/* ---- rpo_gemm_nt for the PROMPT ROWS: a few hundred rows against a frozen weight (ABI 7) -------------------------------
+ * Same contract as rpo_gemm_nt (C = A . W^T with the fused epilogues above; replaces nn.Linear's matmul,
+ * clip/model.py:173-177,186, and autograd's mm(dY, W), trainers/rpo.py:308, for the B*K / n_cls*K prompt rows of the
+ * two towers), except that W is the FRAGMENT-MAJOR copy rpo_gemm_ws_pack made of the [N, K] weight once at load time:
+ * the weight operand then streams global -> VGPR in MFMA fragment order (1 KiB per wave-instruction, no LDS), the four
+ * waves of a workgroup split the contraction, and the tile (32x32 .. 96x96) is chosen so that the launch covers the CUs
+ * about once (rpo_amd/csrc/gemm_ws.hip).  args->W = the packed copy, args->ldw is ignored.
+ *   16-bit inputs only (RPO_E_DTYPE otherwise); K % 64 == 0, N % 32 == 0; epilogues NONE (16-bit or fp32 C; split_k slabs
+ *   as rpo_gemm_nt), QGELU_BWD, BIAS, BIAS_QGELU, LN_BIAS, LN_BIAS_QGELU (K / ln_group <= 16), BIAS_RESID (fp32 C;
+ *   out2 / ln_stats over 64-column groups); no skip_*, row units or hi / lo residual (RPO_E_SHAPE: use rpo_gemm_nt).
+ *   tile_config: 0 = choose; 100 * MT + 10 * NT forces MT x NT MFMA tiles per workgroup (110, 120, 220, 330).
+ * Deterministic; the k sum is split in four, so the last bits differ from rpo_gemm_nt's. */
+int rpo_gemm_ws(const rpo_gemm_args* args, void* stream);
+/* Wp[N * K] (act dtype, 16-byte aligned) <- W[N, K] row-major (ldw in elements): piece ((nb * K/16 + ks) * 64 + lane) of 8
+ * elements = W[nb * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 ..].  N % 32 == 0, K % 64 == 0. */
+int rpo_gemm_ws_pack(const void* W, int64_t ldw, void* Wp, int N, int K, int dtype, void* stream);
+/* 1 if rpo_gemm_ws takes these shapes / dtypes / epilogue (pointers are not looked at), else 0 */
+int rpo_gemm_ws_ok(const rpo_gemm_args* args);
 
 /* The partial-statistics layout (rpo_gemm_args.ln_group: 64 or 96) a BIAS_RESID producer writes for these shapes,
  * dtypes and row units when the kernel choice is left to the library (tile_config 0).  Only M, N, K, lda, ldw, the

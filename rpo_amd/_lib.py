@@ -102,6 +102,9 @@ SIGNATURES = {
     "rpo_gemm_hilo_ok": (c_i32, [C.POINTER(GemmArgs)]),
     "rpo_error_string": (C.c_char_p, [c_i32]),
     "rpo_gemm_nt": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "rpo_gemm_ws": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "rpo_gemm_ws_pack": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "rpo_gemm_ws_ok": (c_i32, [C.POINTER(GemmArgs)]),
     "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
     "rpo_mlp_fused": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp, c_i32, c_vp]),
     "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),

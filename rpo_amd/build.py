@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpo_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip", "chain.hip"]
+SOURCES = ["gemm.hip", "gemm_ws.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip", "chain.hip"]
 # preprocess.hip reproduces Pillow's double-precision coefficient math bit for bit: no FMA contraction
 EXTRA_FLAGS = {"preprocess.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

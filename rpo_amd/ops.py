@@ -106,6 +106,71 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int =
     return out
 
 
+class PackedWeight:
+    """A frozen [N, K] weight in rpo_gemm_ws's fragment-major order (rpo_gemm_ws_pack): what `gemm_ws` takes as W."""
+    __slots__ = ("data", "N", "K", "dtype")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int):
+        self.data, self.N, self.K, self.dtype = data, N, K, data.dtype
+
+    # the prefetch hint names its bytes (ops.gemm_args: prefetch=...)
+    def is_contiguous(self) -> bool:
+        return True
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def numel(self) -> int:
+        return self.data.numel()
+
+    def element_size(self) -> int:
+        return self.data.element_size()
+
+
+def gemm_ws_pack(w: torch.Tensor) -> PackedWeight:
+    """Fragment-major copy of a row-major 16-bit [N, K] weight (N % 32 == 0, K % 64 == 0)."""
+    N, K = w.shape
+    out = torch.empty(N * K, dtype=w.dtype, device=w.device)
+    check(_lib.load().rpo_gemm_ws_pack(w.data_ptr(), _ld(w), out.data_ptr(), N, K, dtype_code(w.dtype), _stream()),
+          "rpo_gemm_ws_pack")
+    return PackedWeight(out, N, K)
+
+
+class _WView:
+    """stand-in for the weight tensor in gemm_args (shape / dtype / pointer of the packed copy)"""
+    def __init__(self, pw: PackedWeight):
+        self.shape, self.dtype, self._pw = (pw.N, pw.K), pw.dtype, pw
+
+    def data_ptr(self) -> int:
+        return self._pw.data_ptr()
+
+    def dim(self) -> int:
+        return 2
+
+    def stride(self, i: int) -> int:
+        return (self._pw.K, 1)[i]
+
+
+def gemm_ws(a: torch.Tensor, w: PackedWeight, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> torch.Tensor:
+    """out = a @ W.T with a fused epilogue for the prompt rows (rpo_gemm_ws): `w` is the packed copy of W; keyword
+    arguments as `gemm_args`."""
+    args = gemm_args(a, _WView(w), out, epilogue, **kw)
+    check(_lib.load().rpo_gemm_ws(C.byref(args), _stream()), "rpo_gemm_ws")
+    return out
+
+
+def gemm_ws_ok(M: int, N: int, K: int, dtype: torch.dtype, out_dtype: torch.dtype, epilogue: int, split_k: int = 1,
+               stats: bool = False) -> bool:
+    """Does rpo_gemm_ws take this problem (rpo_gemm_ws_ok)?"""
+    if dtype == torch.float32:
+        return False
+    args = GemmArgs(M=M, N=N, K=K, lda=K, ldw=K, ldc=N, in_dtype=dtype_code(dtype), out_dtype=dtype_code(out_dtype),
+                    epilogue=epilogue, split_k=split_k, split_stride=M * N, skip_row0=-1, skip_col0=-1)
+    if stats:
+        args.ln_stats = 4096
+    return int(_lib.load().rpo_gemm_ws_ok(C.byref(args))) == 1
+
+
 def gemm_nt_pair(g0: dict, g1: dict) -> None:
     """Two small-M GEMMs of the same kind in ONE launch (rpo_gemm_nt_pair): g0 / g1 are the keyword arguments of
     `gemm_nt` (a, w, out, epilogue, ...) of the two problems."""

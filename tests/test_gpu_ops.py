@@ -54,7 +54,7 @@ def test_library_loads_and_probe_layouts():
     """The fragment layouts every MFMA kernel assumes, checked on the device with an
     ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
     o = ops()
-    assert o.version() == 6
+    assert o.version() == 7
     for which, kdim in ((0, 16), (1, 2)):
         g = torch.Generator().manual_seed(which)
         a = torch.randint(-4, 5, (32, kdim), generator=g).float()
@@ -1123,3 +1123,127 @@ def test_peak_probes_are_sane():
     assert 1500.0 < bf["copy_gbs"] < 8100.0, bf
     f32 = o.probe_peaks(dev(), 1)
     assert 80.0 < f32["mfma_tflops"] < 165.0, f32
+
+
+# ------------------------------------------------------------------------------------------
+# rpo_gemm_ws: the prompt-row GEMMs with the weight streamed in fragment order (csrc/gemm_ws.hip)
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,cfg", [(768, 3072, 768, 0), (768, 768, 768, 0), (456, 512, 512, 0), (456, 2048, 512, 0),
+                                       (456, 512, 2048, 0), (96, 768, 768, 0), (200, 160, 64, 110), (200, 160, 128, 120),
+                                       (200, 160, 192, 220), (200, 160, 320, 330), (97, 96, 1024, 330), (33, 64, 256, 220)])
+def test_gemm_ws_epilogues(mode, M, N, K, cfg):
+    """Every epilogue of rpo_gemm_ws against float64 on the values the kernel sees, chain shapes of both towers and
+    small ragged ones (row tails, partial n-tiles, waves without a k-chunk), every tile geometry; and against
+    rpo_gemm_nt on the row-major weight (same inputs: the two differ only in summation order)."""
+    from rpo_amd import _lib as L
+    o = ops()
+    dt = DT[mode]
+    a, w = rnd((M, K), 1, 0.5), rnd((N, K), 2, K ** -0.5)
+    bias, resid, u = rnd((N,), 3), rnd((M, N), 4), rnd((M, N), 5)
+    acc = q(a, mode) @ q(w, mode).t()
+    ad, wd = a.to(dev(), dt), w.to(dev(), dt)
+    wp = o.gemm_ws_pack(wd)
+    bd, rd, ud = bias.to(dev()), resid.to(dev()), u.to(dev())
+    f32tol = 1e-4
+    kw = dict(tile_config=cfg)
+    out = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+    close(o.gemm_ws(ad, wp, out, L.EPI_NONE, **kw), acc, mode, "ws none")
+    close(o.gemm_ws(ad, wp, out, L.EPI_BIAS, bias=bd, **kw), acc + bias.double(), mode, "ws bias")
+    of = torch.full((M, N), float("nan"), device=dev())
+    close(o.gemm_ws(ad, wp, of, L.EPI_NONE, **kw), acc, mode, "ws none f32-out", tol=f32tol)
+    ref_nt = torch.empty(M, N, device=dev())
+    o.gemm_nt(ad, wd, ref_nt, L.EPI_NONE)
+    close(of, ref_nt.double().cpu(), "f32", "ws vs gemm_nt", tol=2e-5)
+    close(o.gemm_ws(ad, wp, of, L.EPI_BIAS_RESID, bias=bd, resid=rd, **kw), acc + bias.double() + resid.double(), mode,
+          "ws resid", tol=f32tol)
+    # split-K slabs (fp32), summed in order by the consumer
+    for S in (2, 4):
+        if K // 64 >= S:
+            slabs = torch.full((S, M + 3, N), float("nan"), device=dev())[:, :M]
+            o.gemm_ws(ad, wp, slabs, L.EPI_NONE, split_k=S, **kw)
+            close(slabs.sum(0), acc, mode, f"ws split-K {S}", tol=f32tol)
+    # QuickGELU forward with the saved operand of the bottom rows (both forms), and its backward (both forms)
+    row0 = M // 3
+    pre = acc + bias.double()
+    aux = torch.full((M - row0, N), float("nan"), device=dev())
+    close(o.gemm_ws(ad, wp, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux, aux_row0=row0, **kw), R.qgelu(pre), mode, "ws qgelu")
+    close(aux, pre[row0:], mode, "ws qgelu saved u", tol=f32tol)
+    aux16 = torch.full((M - row0, N), float("nan"), dtype=dt, device=dev())
+    close(o.gemm_ws(ad, wp, out, L.EPI_BIAS_QGELU, bias=bd, aux=aux16, aux_row0=row0, **kw), R.qgelu(pre), mode, "ws qgelu (aux16)")
+    close(aux16, R.qgelu_grad(pre[row0:]), mode, "ws qgelu saved derivative")
+    close(o.gemm_ws(ad, wp, out, L.EPI_QGELU_BWD, aux=ud, **kw), acc * R.qgelu_grad(u.double()), mode, "ws qgelu bwd")
+    d16 = R.qgelu_grad(u.double()).float().to(dev(), dt)
+    close(o.gemm_ws(ad, wp, out, L.EPI_QGELU_BWD, aux=d16, **kw), acc * d16.double().cpu(), mode, "ws qgelu bwd (aux16)")
+    # deterministic: the same launch twice gives the same bits
+    out2 = torch.empty_like(out)
+    o.gemm_ws(ad, wp, out2, L.EPI_QGELU_BWD, aux=d16, **kw)
+    assert torch.equal(out, out2)
+    # the prefetch hint changes nothing
+    o.gemm_ws(ad, wp, out2, L.EPI_QGELU_BWD, aux=d16, prefetch=wp, **kw)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("M,d,N", [(456, 512, 2048), (768, 768, 3072), (100, 1024, 256)])
+def test_gemm_ws_layernorm_fold(mode, M, d, N):
+    """The LayerNorm fold on rpo_gemm_ws, both sides: BIAS_RESID leaves out2 and 64-column partial statistics, the
+    LN_BIAS / LN_BIAS_QGELU consumer reproduces quickgelu(LN(x) W^T + b) (clip/model.py:156-159 feeding :174-175, :186);
+    producer and consumer are interchangeable with rpo_gemm_nt's (same statistics layout)."""
+    from rpo_amd import _lib as L
+    o = ops()
+    dt = DT[mode]
+    att, w_out, b_out = rnd((M, d), 1, 0.5), rnd((d, d), 2, d ** -0.5), rnd((d,), 3)
+    resid = rnd((M, d), 4, 2.0) + 0.4
+    w, b = rnd((N, d), 5, d ** -0.5), rnd((N,), 6)
+    gamma, beta = rnd((d,), 7, 0.1) + 1.0, rnd((d,), 8, 0.05)
+    xm = torch.full((M, d), float("nan"), device=dev())
+    xb = torch.full((M, d), float("nan"), dtype=dt, device=dev())
+    stats = torch.full((M, d // 64, 2), float("nan"), device=dev())
+    wo_d = w_out.to(dev(), dt)
+    o.gemm_ws(att.to(dev(), dt), o.gemm_ws_pack(wo_d), xm, L.EPI_BIAS_RESID, bias=b_out.to(dev()), resid=resid.to(dev()),
+              out2=xb, ln_stats=stats)
+    xm64 = xm.double().cpu()
+    close(xm, q(att, mode) @ q(w_out, mode).t() + b_out.double() + resid.double(), "f32", "ws producer result", tol=1e-4)
+    assert torch.equal(xb.cpu(), xm.cpu().to(dt)), "out2 must be the RNE act-dtype copy of C"
+    grp = xm64.reshape(M, d // 64, 64)
+    ref_stats = torch.stack([grp.mean(-1), ((grp - grp.mean(-1, keepdim=True)) ** 2).sum(-1)], -1)
+    close(stats, ref_stats, "f32", "ws partial row statistics", tol=2e-5)
+    wq = (w.double() * gamma.double()[None, :]).float().to(dt)
+    s = wq.double().sum(1).float()
+    bq = (b.double() + w.double() @ beta.double()).float()
+    mu = xm64.mean(1, keepdim=True)
+    rstd = (xm64.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    pre = ((xm64 - mu) * rstd * gamma.double() + beta.double()) @ w.double().t() + b.double()
+    row0 = M // 2
+    wqp = o.gemm_ws_pack(wq.to(dev()))
+    for cfg in (0, 110, 220, 330):
+        y = torch.full((M, N), float("nan"), dtype=dt, device=dev())
+        aux16 = torch.full((M - row0, N), float("nan"), dtype=dt, device=dev())
+        o.gemm_ws(xb, wqp, y, L.EPI_LN_BIAS_QGELU, bias=bq.to(dev()), aux=aux16, aux_row0=row0, ln_stats=stats,
+                  ln_colsum=s.to(dev()), tile_config=cfg)
+        close(y, R.qgelu(pre), mode, f"ws LN-folded c_fc cfg {cfg}", tol=1.5 * TOL[mode])
+        close(aux16, R.qgelu_grad(pre[row0:]), mode, f"ws LN-folded saved derivative cfg {cfg}", tol=1.5 * TOL[mode])
+        o.gemm_ws(xb, wqp, y, L.EPI_LN_BIAS, bias=bq.to(dev()), ln_stats=stats, ln_colsum=s.to(dev()), tile_config=cfg)
+        close(y, pre, mode, f"ws LN-folded in-proj cfg {cfg}", tol=1.5 * TOL[mode])
+    # statistics written by rpo_gemm_nt's producer feed the ws consumer the same way
+    stats2 = torch.full_like(stats, float("nan"))
+    xb2 = torch.empty_like(xb)
+    xm2 = torch.empty_like(xm)
+    o.gemm_nt(att.to(dev(), dt), wo_d, xm2, L.EPI_BIAS_RESID, bias=b_out.to(dev()), resid=resid.to(dev()), out2=xb2, ln_stats=stats2)
+    close(stats2, ref_stats, "f32", "nt partial statistics vs ws result", tol=1e-4)
+
+
+def test_gemm_ws_refuses_what_it_does_not_cover():
+    from rpo_amd import _lib as L
+    o = ops()
+    assert o.gemm_ws_ok(768, 3072, 768, torch.bfloat16, torch.bfloat16, L.EPI_QGELU_BWD)
+    assert o.gemm_ws_ok(456, 512, 2048, torch.float16, torch.float32, L.EPI_NONE, split_k=4)
+    assert not o.gemm_ws_ok(768, 3072, 768, torch.float32, torch.float32, L.EPI_NONE)          # f32 mode: rpo_gemm_nt
+    assert not o.gemm_ws_ok(768, 3080, 768, torch.bfloat16, torch.bfloat16, L.EPI_NONE)        # N % 32
+    assert not o.gemm_ws_ok(768, 3072, 800, torch.bfloat16, torch.bfloat16, L.EPI_NONE)        # K % 64
+    assert not o.gemm_ws_ok(768, 768, 768, torch.bfloat16, torch.bfloat16, L.EPI_NONE, split_k=2)   # slabs are fp32
+    assert not o.gemm_ws_ok(768, 768, 3072, torch.bfloat16, torch.bfloat16, L.EPI_LN_BIAS)     # 48 statistics groups
+    a = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev())
+    wp = o.gemm_ws_pack(torch.zeros(64, 64, dtype=torch.bfloat16, device=dev()))
+    with pytest.raises(Exception):
+        o.gemm_ws(a, wp, torch.zeros(64, 64, dtype=torch.bfloat16, device=dev()), L.EPI_NONE, skip_row0=0, skip_col0=0)
