@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const WsParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
+  RPO_STAMP(0); RPO_STAMP_RT(62);
 
   // ---- workgroup -> (m-tile, n-tile, k-split): XCD x = bid % 8 takes a contiguous run of the linear order
   //      ((split, n-tile), m-tile), m fastest
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const WsParams p) {
         areg[j] = *reinterpret_cast<const bf16x8_t*>(src + 128 + aoff[j]);                                               \
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    RPO_STAMP(2);                                                                                                        \
   }
   // one chunk; REFRESH: re-request the weight fragments for chunk i+1; PARK: park chunk i+1 (in areg) into the other slot;
   // LOAD: request chunk i+2 into areg
@@ -259,7 +261,9 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const WsParams p) {
       }                                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);   /* or hipcc sinks every request of the chunk behind its last MFMA */          \
     }                                                                                                                    \
+    RPO_STAMP(3 + (i < 40 ? i : 40));                                                                                    \
   }
+  RPO_STAMP(1);
   // Three separate code paths by chunk count, so that every join the waitcnt pass sees has the same requests pending on
   // all its edges (a shared prologue with `if (nc > 1)` around the chunk-1 request made the loop's waits those of nc = 1)
   if (nc >= 3) {
@@ -333,7 +337,9 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const WsParams p) {
       row_stats[tid] = ws_ln_finish(mu, m2, sq, G, p.K, p.ln_eps);
     }
   }
+  RPO_STAMP(58);
   ws_lds_barrier();                                 // every wave is done with its ring: the staging image may overwrite it
+  RPO_STAMP(59);
   TOut* const cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)ksl * p.split_stride;
   auto park = [&](const int tm) {
     char* mine = smem + (tm & 1) * (4 * CF::PART_BYTES) + wave * CF::PART_BYTES;
@@ -427,6 +433,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(const WsParams p) {
       }
     }
   }
+#ifdef RPO_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(61); RPO_STAMP_RT(63);
   asm volatile("" :: "v"(pf_touch));                // (keeps the touch register reserved to the end)
 }
 

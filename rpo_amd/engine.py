@@ -82,6 +82,11 @@ class Engine:
         # prefetch hints on the prompt-row chains (text tower, both backward chains): A/B switch RPO_NO_CHAIN_PREFETCH=1
         self._pf_chains = (act_dtype != torch.float32 and os.environ.get("RPO_NO_WPREFETCH") != "1"
                            and os.environ.get("RPO_NO_CHAIN_PREFETCH") != "1")
+        # The prompt-row GEMMs (text tower, last image block, both backward chains) on rpo_gemm_ws: the frozen weight packed
+        # fragment-major once at load and streamed global -> VGPR (csrc/gemm_ws.hip).  16-bit modes; A/B switch RPO_NO_WS=1.
+        self.use_ws = act_dtype != torch.float32 and os.environ.get("RPO_NO_WS") != "1"
+        self._wsp: Dict[tuple, "ops.PackedWeight"] = {}   # (data_ptr, shape) of a row-major weight -> its packed twin
+        self._ws_okc: Dict[tuple, bool] = {}
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -141,17 +146,69 @@ class Engine:
 
     def _oq_t(self, w_out: torch.Tensor, w_q: torch.Tensor) -> dict:
         """The two d x d dX weights of the attention backward in ONE allocation, so that one prefetch hint
-        (rpo_gemm_args.prefetch) covers both: the d out-proj operand is read first, the d q-proj operand next."""
+        (rpo_gemm_args.prefetch) covers both: the d out-proj operand is read first, the d q-proj operand next.
+        With rpo_gemm_ws the allocation has four slots, [w_q_t | w_out_t | packed w_q_t | packed w_out_t]: the image
+        tower's chain reads slots 1-2 (the attention backward folds d out-proj in and reads the row-major matrix, the
+        d q-proj GEMM the packed one), a chain without the fold slots 2-3 (`_oq_hint`)."""
         d = w_out.shape[0]
-        both = torch.empty(2, d, d, dtype=self.act, device=self.dev)
-        both[0].copy_(self._act(w_out.t()))
-        both[1].copy_(self._act(w_q.t()))
-        return dict(w_out_t=both[0], w_q_t=both[1], w_oq_t=both)
+        if not self.use_ws:
+            both = torch.empty(2, d, d, dtype=self.act, device=self.dev)
+            both[0].copy_(self._act(w_out.t()))
+            both[1].copy_(self._act(w_q.t()))
+            return dict(w_out_t=both[0], w_q_t=both[1], w_oq_t=both)
+        both = torch.empty(4, d, d, dtype=self.act, device=self.dev)
+        both[0].copy_(self._act(w_q.t()))
+        both[1].copy_(self._act(w_out.t()))
+        for src, dst in ((0, 2), (1, 3)):
+            pw = ops.gemm_ws_pack(both[src])
+            both[dst].view(-1).copy_(pw.data)
+            self._wsp[(both[src].data_ptr(), (d, d))] = ops.PackedWeight(both[dst].view(-1), d, d)
+        return dict(w_out_t=both[1], w_q_t=both[0], w_oq_t=both)
+
+    def _oq_hint(self, blk: _Block, fold_out: bool) -> torch.Tensor:
+        if not self.use_ws:
+            return blk.w_oq_t
+        return blk.w_oq_t[1:3] if fold_out else blk.w_oq_t[2:4]
+
+    def _ws_reg(self, w: Optional[torch.Tensor]) -> None:
+        """Packs a frozen row-major [N, K] weight for rpo_gemm_ws (once) and files the copy under the tensor's address."""
+        if not self.use_ws or w is None or w.dim() != 2 or w.dtype != self.act or w.stride(1) != 1:
+            return
+        N, K = w.shape
+        key = (w.data_ptr(), (N, K))
+        if key in self._wsp or N % 32 != 0 or K % 64 != 0:
+            return
+        self._wsp[key] = ops.gemm_ws_pack(w)
+
+    def _gemm(self, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> torch.Tensor:
+        """out = a @ w.T (+ epilogue) for the prompt rows: rpo_gemm_ws where the weight has a packed twin and the kernel takes
+        the problem, else rpo_gemm_nt.  A prefetch hint that names a weight with a packed twin names the twin instead
+        (that is what the next launch reads)."""
+        pw = self._wsp.get((w.data_ptr(), tuple(w.shape))) if self.use_ws else None
+        if pw is not None:
+            M, split = a.shape[0], kw.get("split_k", 1)
+            key = (M, pw.N, pw.K, out.dtype, epilogue, split, kw.get("ln_stats") is not None and epilogue == EPI_BIAS_RESID)
+            ok = self._ws_okc.get(key)
+            if ok is None:
+                ok = self._ws_okc[key] = (M < 2048 and ops.gemm_ws_ok(M, pw.N, pw.K, self.act, out.dtype, epilogue, split, key[-1]))
+            if ok:
+                pf = kw.get("prefetch")
+                if pf is not None:
+                    kw["prefetch"] = self._wsp.get((pf.data_ptr(), tuple(pf.shape)), pf)
+                return ops.gemm_ws(a, pw, out, epilogue, **kw)
+        return ops.gemm_nt(a, w, out, epilogue, **kw)
 
     def _pack(self, sd, tokens) -> None:
         cfg = self.cfg
         self.vis = [self._block(sd, f"visual.transformer.resblocks.{l}.", fold=self.fold_ln) for l in range(cfg.layers_v)]
         self.txt = [self._block(sd, f"transformer.resblocks.{l}.", fold=self.fold_ln) for l in range(cfg.layers_t)]
+        # packed twins (rpo_gemm_ws) of every weight a prompt-row GEMM reads: the dX operands of both chains, the text
+        # tower's forward weights (its q rows of the in-projection only) and the last image block's (prompt rows only)
+        for blk in self.vis + self.txt:
+            self._ws_reg(blk.w_proj_t); self._ws_reg(blk.w_fc_t)
+        for blk, d in [(b, cfg.d_t) for b in self.txt] + ([(self.vis[-1], cfg.d_v)] if self.vis else []):
+            for w in (blk.w_in[:d], None if blk.w_in_ln is None else blk.w_in_ln[:d], blk.w_out, blk.w_fc, blk.w_fc_ln, blk.w_proj):
+                self._ws_reg(w)
         self.kpatch = _round_up(cfg.patch_dim, self.kmult)
         conv = torch.zeros(cfg.d_v, self.kpatch, device=self.dev)
         conv[:, :cfg.patch_dim] = self._f32(sd["visual.conv1.weight"]).reshape(cfg.d_v, -1)
@@ -164,6 +221,8 @@ class Engine:
         vp, tp = self._f32(sd["visual.proj"]), self._f32(sd["text_projection"])      # [d, e]
         self.img_proj_t, self.img_proj = self._act(vp.t()), self._act(vp)           # fwd W=[e,d]; bwd W=[d,e]
         self.text_proj_t, self.text_proj = self._act(tp.t()), self._act(tp)
+        for w in (self.img_proj_t, self.img_proj, self.text_proj_t, self.text_proj):
+            self._ws_reg(w)
         # make_prompts (trainers/rpo.py:135-136): tok_emb[ids] + pos, kept for the frozen tokens only
         tx = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][None]
         self.text_x_frozen = self._f32(tx[:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
@@ -206,7 +265,7 @@ class Engine:
         # backward temporaries (prompt rows)
         self.d_img_f = f32(Rp, e)
         self.d_img_f_a = a(Rp, e)
-        self.dy_v = f32(max(SPLIT_FC, SPLIT_Q), Rp, dv)
+        self.dy_v = f32(max(SPLIT_FC, SPLIT_Q, 4), Rp, dv)       # (rpo_gemm_ws splits d c_fc in up to four)
         # the persistent backward chain (rpo_chain_bwd): 4 k-slice slabs, its scratch (one per tower: the two chains run
         # concurrently), optional stage timeline (tools/chain_timeline.py sets it)
         self.dy4_v = f32(4, Rp, dv)
@@ -232,7 +291,7 @@ class Engine:
         self.d_text_f = f32(Rt, e)
         self.d_text_f_a = a(Rt, e)
         self.ln_stats_t = f32(Rt, dt // 64, 2)
-        self.dy_t = f32(max(SPLIT_FC, SPLIT_Q), Rt, dt)
+        self.dy_t = f32(max(SPLIT_FC, SPLIT_Q, 4), Rt, dt)
         self.dy4_t = f32(4, Rt, dt)
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
@@ -309,30 +368,30 @@ class Engine:
             # LayerNorm folded into the GEMMs around it exactly as in the image tower (_image_forward): the residual
             # GEMMs leave the 16-bit copy of their result in ht and its row statistics in st
             if fold and l > 0:
-                ops.gemm_nt(self.ht, blk.w_in_ln[:dt], self.qt[l], EPI_LN_BIAS, bias=blk.b_in_ln[:dt], ln_stats=st,
+                self._gemm(self.ht, blk.w_in_ln[:dt], self.qt[l], EPI_LN_BIAS, bias=blk.b_in_ln[:dt], ln_stats=st,
                             ln_colsum=blk.s_in[:dt], prefetch=blk.w_out if pf else None)
             else:
                 ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
-                ops.gemm_nt(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt],
+                self._gemm(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt],
                             prefetch=blk.w_out if pf else None)
             ops.text_attn_fwd(self.qt[l], kv[:, :dt], kv[:, dt:], self.att_t, self.len_i32, n, K, self.Lmax, H,
                               causal=False, scale=SCALE)
             prod = dict(out2=self.ht, ln_stats=st) if fold else {}
-            ops.gemm_nt(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod,
+            self._gemm(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod,
                         prefetch=(blk.w_fc_ln if fold else blk.w_fc) if pf else None)
             if fold:
-                ops.gemm_nt(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                self._gemm(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                             aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc,
                             prefetch=blk.w_proj if pf else None)
             else:
                 ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
-                ops.gemm_nt(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
+                self._gemm(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
                             aux=self.ut[l] if train else None, aux_row0=0, prefetch=blk.w_proj if pf else None)
             prod = dict(out2=self.ht, ln_stats=st) if (fold and l < last) else {}
-            ops.gemm_nt(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod,
+            self._gemm(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod,
                         prefetch=nxt_q(l))
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
-        ops.gemm_nt(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
+        self._gemm(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 
     def _image_forward(self, image: torch.Tensor, train: bool, full_last: bool = False) -> None:
         cfg = self.cfg
@@ -449,7 +508,7 @@ class Engine:
                 # i_f of :211 is dead code), and no later block reads the frozen rows.  So the frozen rows contribute
                 # their K / V and nothing else: q and everything after attention run on the B*K prompt rows only.
                 ops.gemm_nt(h[:Rf], w_in[dv:], qkv[:Rf, dv:], epi_in, bias=b_in[dv:], **lnk(0, Rf, dv, 3 * dv))
-                ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv, own=split))
+                self._gemm(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv, own=split))
                 ops.attn_readonly_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], att, B, H, N, K, SCALE,
                                       q_first=N)
                 segs = [(Rf, R, False)]
@@ -470,9 +529,11 @@ class Engine:
                 res_o = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if (hl and l > 0) else dict(resid=x[lo:hi])
                 if hl:
                     prod.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)             # (h_lo None: the hi half alone)
+                # (prompt rows alone -- the last block, the split mode -- go to rpo_gemm_ws where the weight has a packed twin)
+                gemm = ops.gemm_nt if wide else self._gemm
                 with timed("out_proj"):
-                    ops.gemm_nt(att[lo:hi], blk.w_out, xm[lo:hi], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
-                                **res_o, **prod, prefetch=pf_of("out", l) if wide else None)
+                    gemm(att[lo:hi], blk.w_out, xm[lo:hi], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
+                         **res_o, **prod, prefetch=pf_of("out", l) if wide else None)
                 # c_proj + residual; folded: copy + statistics of x[l+1] for the next block's in-proj
                 prod_p = dict(out2=h[lo:hi], ln_stats=sp[lo:hi], ln_group=gp) if (fold and l < last) else {}
                 res_p = dict(resid_hi=h[:hi], resid_lo=None if h_lo is None else h_lo[:hi]) if hl else dict(resid=xm[lo:hi])
@@ -480,6 +541,8 @@ class Engine:
                     prod_p.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)
                 proj_kw = dict(a=g[lo:hi], w=blk.w_proj, out=xo[lo:hi], epilogue=EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
                                **res_p, **prod_p, prefetch=pf_of("proj", l) if wide else None)
+                if not wide:                  # (64-column statistics either way; no row units)
+                    proj_kw.pop("row_units"); proj_kw.pop("ln_group", None)
                 # EXPERIMENT (round 4, RPO_MLP_FUSED=1 / =safe): c_fc -> c_proj of a whole-batch block as ONE launch
                 # (rpo_mlp_fused: the 8 workgroups of an image hand g over through their XCD's L2 at a counter)
                 if fold and wide and mlp_fused:
@@ -492,20 +555,24 @@ class Engine:
                         continue
                 if fold:
                     with timed("c_fc"):
-                        ops.gemm_nt(h[lo:hi], blk.w_fc_ln, g[lo:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
-                                    aux=aux, aux_row0=aux_row0,
-                                    ln_stats=so[lo:hi], ln_colsum=blk.s_fc, row_units=un, ln_group=go,
-                                    prefetch=pf_of("fc", l) if wide else None)
+                        gemm(h[lo:hi], blk.w_fc_ln, g[lo:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
+                             aux=aux, aux_row0=aux_row0,
+                             ln_stats=so[lo:hi], ln_colsum=blk.s_fc, row_units=un, ln_group=go,
+                             prefetch=pf_of("fc", l) if wide else None)
                 else:
                     with timed("ln_2"):
                         ops.layernorm_fwd(xm[lo:hi], blk.ln2_w, blk.ln2_b, h[lo:hi])
                     with timed("c_fc"):
-                        ops.gemm_nt(h[lo:hi], blk.w_fc, g[lo:hi], EPI_BIAS_QGELU, bias=blk.b_fc,
-                                    aux=aux, aux_row0=aux_row0, row_units=un)
+                        gemm(h[lo:hi], blk.w_fc, g[lo:hi], EPI_BIAS_QGELU, bias=blk.b_fc,
+                             aux=aux, aux_row0=aux_row0, row_units=un)
                 with timed("c_proj"):
-                    ops.gemm_nt(**proj_kw)
+                    if wide:
+                        ops.gemm_nt(**proj_kw)
+                    else:
+                        pk = dict(proj_kw)
+                        self._gemm(pk.pop("a"), pk.pop("w"), pk.pop("out"), pk.pop("epilogue"), **pk)
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
-        ops.gemm_nt(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
+        self._gemm(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 
     def _split_rows(self, B: int) -> bool:
         """Whether the image forward runs its frozen rows and its prompt rows as separate launches (see _image_forward):
@@ -531,6 +598,12 @@ class Engine:
         """Shared by both towers: dx (fp32, in dxa) holds dL/d(block output) on entry; on return the
         tensor holding dL/d(block-0 input).  dxc mirrors dx in the act dtype (GEMM A operand)."""
         pf = self._pf_chains
+        # split-K factors of the two fp32-output dX GEMMs (slabs summed in fixed order by rpo_layernorm_bwd).  On
+        # rpo_gemm_ws the waves of a workgroup already split k four ways: d q-proj runs unsplit (one slab less for the
+        # LayerNorm backward to read) and d c_fc in 4 (K = 4d >= 3072: 96x96 tiles x 4 = one round of the CUs at
+        # 768 rows) or 2 (the text tower's K = 2048) -- tools/bench_gemm_ws.py, profiles/r05_bench_gemm_ws.txt
+        d = blocks[0].w_q_t.shape[0] if blocks else 0
+        s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not self.use_ws else ((4 if dxa.shape[0] >= 256 else 3) if d >= 768 else 2, 1)
         for l in reversed(range(len(blocks))):
             blk = blocks[l]
             a_in = dxa if self.act == torch.float32 else dxc
@@ -540,20 +613,21 @@ class Engine:
             #  the frozen rows' K / V of the block, 29 MB, named by this GEMM for the attention backward two kernels on:
             #  step 1.8 % SLOWER, 3.045 vs 2.992 ms; the saved QuickGELU operand u[l-1], named by the d q-proj GEMM: no
             #  effect, 2.875 vs 2.871 ms)
-            ops.gemm_nt(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None)  # d c_proj, d QuickGELU
-            ops.gemm_nt(du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC,
-                        prefetch=blk.w_oq_t if pf else None)                     # d c_fc
-            ops.layernorm_bwd(dy[:SPLIT_FC], xm[l], blk.ln2_w, dxa, dxb,
+            self._gemm(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None)  # d c_proj, d QuickGELU
+            self._gemm(du, blk.w_fc_t, dy[:s_fc], EPI_NONE, split_k=s_fc,
+                       prefetch=self._oq_hint(blk, fold_out) if pf else None)                     # d c_fc
+            ops.layernorm_bwd(dy[:s_fc], xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
             if fold_out:
                 attn_bwd(l, a_in, dq)                                             # d out_proj inside the attention kernel
             else:
-                ops.gemm_nt(a_in, blk.w_out_t, da, EPI_NONE)                      # d out_proj
+                self._gemm(a_in, blk.w_out_t, da, EPI_NONE)                       # d out_proj
                 attn_bwd(l, da, dq)
-            ops.gemm_nt(dq, blk.w_q_t, dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q,
-                        prefetch=blocks[l - 1].w_proj_t if (pf and l > 0) else None)   # d q-projection
-            ops.layernorm_bwd(dy[:SPLIT_Q], x[l], blk.ln1_w, dxb, dxa,
+            dyq = dy[0] if s_q == 1 else dy[:s_q]
+            self._gemm(dq, blk.w_q_t, dyq, EPI_NONE, split_k=s_q,
+                       prefetch=blocks[l - 1].w_proj_t if (pf and l > 0) else None)   # d q-projection
+            ops.layernorm_bwd(dyq, x[l], blk.ln1_w, dxb, dxa,
                               None if self.act == torch.float32 else dxc)
         return dxa
 
@@ -577,8 +651,8 @@ class Engine:
             d_f = self.d_img_f[r0:r1]
         else:
             d_f = self.d_img_f_a[r0:r1]                # written by the head's backward
-        ops.gemm_nt(d_f, self.img_proj, self.dy_v[0, r0:r1], EPI_NONE,
-                    prefetch=self.vis[-1].w_proj_t if self._pf_chains else None)
+        self._gemm(d_f, self.img_proj, self.dy_v[0, r0:r1], EPI_NONE,
+                   prefetch=self.vis[-1].w_proj_t if self._pf_chains else None)
         ops.layernorm_bwd(self.dy_v[0, r0:r1], self.x[-1][Rf + r0:Rf + r1], self.ln_post[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
@@ -725,8 +799,8 @@ class Engine:
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
         d_f = self.d_text_f if self.act == torch.float32 else self.d_text_f_a      # written by the head's backward
-        ops.gemm_nt(d_f, self.text_proj, self.dy_t[0], EPI_NONE,
-                    prefetch=self.txt[-1].w_proj_t if self._pf_chains else None)
+        self._gemm(d_f, self.text_proj, self.dy_t[0], EPI_NONE,
+                   prefetch=self.txt[-1].w_proj_t if self._pf_chains else None)
         ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 

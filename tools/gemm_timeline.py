@@ -7,7 +7,7 @@ import torch
 from rpo_amd import _lib, ops
 from rpo_amd._lib import EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_NONE
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
-src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip", "chain.hip")]
+src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "gemm_ws.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip", "preprocess.hip", "chain.hip")]
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
     # (compiler output goes to a log next to the library, not into the timeline this script prints)
