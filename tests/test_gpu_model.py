@@ -1038,6 +1038,9 @@ def test_joint_backward_equals_the_two_chains(monkeypatch, B):
     # (the paired form runs the text tower's attention backward on the MFMA kernel with d out-proj folded in: the two-chain
     #  run is given the same kernel, RPO_TEXT_BWD_FOLD=1, so that the comparison is launch structure only)
     monkeypatch.setenv("RPO_TEXT_BWD_FOLD", "1")
+    # (... and both runs keep the chains' GEMMs on rpo_gemm_nt, which is what the paired launch pairs: the default chains
+    #  run them on rpo_gemm_ws since round 5, whose four-way k split gives other last bits)
+    monkeypatch.setenv("RPO_NO_WS", "1")
     for joint in ("1", "0"):
         monkeypatch.setenv("RPO_JOINT_BWD", joint)
         tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=10 ** 9, prompts=(tp, ip))
