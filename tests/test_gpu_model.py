@@ -74,6 +74,36 @@ def test_f32_prompt_rows_per_block():
         assert np.abs(rows - g["text_rows"][l]).max() <= TOL_F32, f"text block {l}"
 
 
+def test_f32_vitl14_blocks_match_reference_modules():
+    """ViT-L/14 widths (width 1024 / 16 heads / 257 + 24 tokens; text width 768 / 12 heads) against the reference's own
+    CustomCLIP run at those widths (tools/make_golden_vitl14_ref.py: `ref_vitl14_d2_k24_b2.npz`, 2 + 2 layers): the
+    prompt rows after every block of both towers, eval logits, loss and both gradients, fp32 mode within 1e-3."""
+    from rpo_amd.config import vit_l14
+    from rpo_amd.custom_clip import CustomCLIP
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vitl14_d2_k24_b2.npz")))
+    cfg = vit_l14(layers_v=2, layers_t=2, K=24)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    image, label = torch.from_numpy(synth.images(cfg, 2)).cuda(), torch.from_numpy(synth.labels(cfg, 2)).cuda()
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", torch.float32, max_batch=2, prompts=(tp, ip))
+    m.prompt_learner.eval()
+    logits = m(image).cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() <= TOL_F32
+    eng = m.engine
+    eng.forward_backward(image, label)
+    torch.cuda.synchronize()
+    B, N, K = 2, cfg.n_frozen, cfg.K
+    for l in range(cfg.layers_v):
+        rows = eng.x[l + 1][B * N:B * (N + K)].view(B, K, cfg.d_v).cpu().numpy()
+        assert np.abs(rows - g["img_rows"][l]).max() <= TOL_F32, f"image block {l}"
+    for l in range(cfg.layers_t):
+        rows = eng.xt[l + 1].view(cfg.n_cls, K, cfg.d_t)[:4].cpu().numpy()
+        assert np.abs(rows - g["text_rows"][l]).max() <= TOL_F32, f"text block {l}"
+    assert abs(float(eng.loss.item()) - float(g["loss"])) <= TOL_F32
+    assert _relmax(eng.g_text.cpu().numpy(), g["g_text"]) <= TOL_F32 and _relmax(eng.g_img.cpu().numpy(), g["g_img"]) <= TOL_F32
+
+
 @pytest.mark.parametrize("tag", ["d2_k8_b3", "d12_k24_b4"])
 def test_f32_sgd_steps_match_reference(tag):
     from rpo_amd.trainer import RPO, OptimConfig
@@ -461,7 +491,7 @@ _F32_FULL = {}
 # fixture comes from the dense oracle and is named oracle_*.
 FULL_GOLDEN = [("ref_full_k24_b32", "ViT-B/16", 24, 32), ("ref_full_k4_b32", "ViT-B/16", 4, 32),
                ("ref_full_k8_b32", "ViT-B/16", 8, 32), ("ref_full_k16_b32", "ViT-B/16", 16, 32),
-               ("ref_full_k48_b32", "ViT-B/16", 48, 32), ("oracle_vitl14_k24_b16", "ViT-L/14", 24, 16)]
+               ("ref_full_k48_b32", "ViT-B/16", 48, 32), ("ref_full_vitl14_k24_b16", "ViT-L/14", 24, 16)]
 FULL_TOL = {torch.float32: (TOL_F32, TOL_F32), torch.float16: (F16_LOGIT_ATOL, F16_GRAD_REL),
             torch.bfloat16: (BF16_LOGIT_ATOL, BF16_GRAD_REL)}
 
@@ -531,6 +561,52 @@ def test_full_size_sgd_steps_match_reference(act, tol):
         assert et <= tol and ei <= tol
     lt = {torch.float32: TOL_F32, torch.float16: F16_LOGIT_ATOL, torch.bfloat16: BF16_LOGIT_ATOL}[act]
     assert np.abs(np.asarray(losses) - g["sgd_losses"]).max() <= lt
+
+
+# bounds on the LEARNED PROMPTS after the whole run (max abs difference to the reference's, per tensor): the north star's
+# 1e-3 for the fp32 mode; the 16-bit modes' are what was measured on the GPU (printed by the test) with head-room
+TRAJ_TOL = {torch.float32: 1e-3, torch.float16: 2e-3, torch.bfloat16: 1e-2}
+
+
+@pytest.mark.parametrize("act", [torch.float32, torch.float16, torch.bfloat16], ids=lambda v: str(v).replace("torch.", ""))
+def test_sixty_step_trajectory_matches_reference_run(act):
+    """BASELINE configs[0] end to end: 15 epochs x 4 iterations of ViT-B/16, K = 24, batch 4 through RPO.forward_backward
+    -- captured graphs, fused SGD (momentum 0.9, weight decay 5e-4), one constant warm-up epoch at 1e-5, cosine decay,
+    the rate updated after the last batch of every epoch (trainers/rpo.py:306-314, main_K24.yaml:15-22) -- against the
+    REAL reference's run of the same schedule on the same inputs (tools/make_golden_trajectory.py): both prompt tensors
+    after epochs 1, 5 and 15, the learning rate of every epoch, the 60 losses.  This is what "learned prompt embeddings
+    match the reference" means over a run rather than over two steps."""
+    from rpo_amd.trainer import RPO, OptimConfig
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_traj_d12_k24_b4_e15.npz")))
+    lr, mom, wd, max_epoch, iters, B, warm, cons = (float(v) for v in g["hparams"])
+    max_epoch, iters, B, warm = int(max_epoch), int(iters), int(B), int(warm)
+    cfg, sd, toks, tp, ip, _, _ = _full_workload("ViT-B/16", 24, B)
+    oc = OptimConfig(lr=lr, max_epoch=max_epoch, lr_scheduler="cosine", warmup_epoch=warm, warmup_type="constant",
+                     warmup_cons_lr=cons, momentum=mom, weight_decay=wd)
+    tr = RPO(cfg, sd, toks, oc, "cuda:0", act, batch_size=B, num_batches=iters, prompts=(tp, ip))
+    batches = [{"img": torch.from_numpy(synth.images(cfg, B, seed=1234 + 10 * i)),
+                "label": torch.from_numpy(synth.labels(cfg, B, seed=4321 + 10 * i))} for i in range(iters)]
+    losses, worst = [], 0.0
+    for epoch in range(max_epoch):
+        assert abs(tr.lr - float(g["lrs"][epoch])) <= 1e-12 * max(1.0, lr), (epoch, tr.lr, float(g["lrs"][epoch]))
+        for it in range(iters):
+            losses.append(tr.forward_backward(batches[it])["loss"])
+        if f"text_prompt_e{epoch + 1}" in g:
+            t = tr.model.prompt_learner.text_prompt.detach().cpu().numpy()
+            i = tr.model.prompt_learner.img_prompt.detach().cpu().numpy()
+            et, ei = np.abs(t - g[f"text_prompt_e{epoch + 1}"]).max(), np.abs(i - g[f"img_prompt_e{epoch + 1}"]).max()
+            moved = max(np.abs(g[f"text_prompt_e{epoch + 1}"] - tp).max(), np.abs(g[f"img_prompt_e{epoch + 1}"] - ip).max())
+            print(f"[trajectory {act}] after epoch {epoch + 1:2d}: text prompt err {et:.2e} img prompt err {ei:.2e} "
+                  f"(the prompts have moved by up to {moved:.2e})")
+            worst = max(worst, et, ei)
+    le = np.abs(np.asarray(losses) - g["losses"]).max()
+    print(f"[trajectory {act}] 60 losses: max |diff| {le:.2e} (reference {g['losses'][0]:.4f} -> {g['losses'][-1]:.4f})")
+    assert worst <= TRAJ_TOL[act], (worst, TRAJ_TOL[act])
+    lt = {torch.float32: TOL_F32, torch.float16: F16_LOGIT_ATOL, torch.bfloat16: BF16_LOGIT_ATOL}[act]
+    assert le <= lt, (le, lt)
+    tr.model.prompt_learner.eval()
+    logits = tr.model(batches[0]["img"].cuda()).cpu().numpy()
+    assert np.abs(logits - g["final_logits"]).max() <= lt
 
 
 def test_two_ranks_equal_one_rank_global_batch(tmp_path):

@@ -423,3 +423,41 @@ def test_stats_group_query_needs_no_gpu():
     assert g(3536, 768, 768, torch.bfloat16, (197, 24, 3152)) == 64                    # 16 images: half a round
     assert g(16 * 281, 1024, 4096, torch.bfloat16, (257, 24, 16 * 257)) == 64          # ViT-L/14: 288x64 tiles
     assert g(7072, 768, 192, torch.bfloat16, (197, 24, 6304)) == 64                    # K = 192: 3 k-tiles, not admitted
+
+
+def test_committed_profiles_are_measurements_not_crash_logs():
+    """Round 4 committed two Python tracebacks as `r04_*_timeline.txt` (tools/build_debug.sh lacked a translation unit
+    and tools/collect_profiles.sh kept whatever a tool printed).  No tracked profile may hold a traceback or compiler
+    output; collect_profiles.sh keeps a tool's output only on exit status 0; summarize_profiles.py refuses such files;
+    build_debug.sh compiles every source the product library is built from."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*.txt"))):
+        txt = open(f, errors="replace").read()
+        if "Traceback (most recent call last)" in txt or re.search(r"(^|\s)(warning|error):", txt):
+            bad.append(os.path.basename(f))
+    assert not bad, f"profiles that are not measurements: {bad}"
+    sh = open(os.path.join(root, "tools", "collect_profiles.sh")).read()
+    assert "keep()" in sh and "exit 1" in sh and "Traceback (most recent call last)" in sh
+    assert "REFUSED" in open(os.path.join(root, "tools", "summarize_profiles.py")).read()
+    from rpo_amd.build import SOURCES
+    dbg = open(os.path.join(root, "tools", "build_debug.sh")).read()
+    missing = [s for s in SOURCES if s not in dbg]
+    assert not missing, f"tools/build_debug.sh does not compile {missing}: the -DRPO_TIMELINE library would lack ABI symbols"
+
+
+def test_mfma_busy_figure_is_in_one_clock_domain():
+    """The north-star kernel figure in the bench line (roofline.qkv_gemm) is busy shader cycles over (duration x shader
+    clock measured in the kernel) whenever the committed summary holds it, and says which summary it came from."""
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    res = bench.committed_qkv_gemm(types.SimpleNamespace(model="ViT-B/16", K=24, batch=32, dtype="bf16"))
+    assert res is not None and res["target"] == 0.70 and res["source"].startswith("profiles/")
+    if "stale" not in res and "mfma_busy" in res:
+        lo, hi = sorted((res.get("mfma_busy_wall", 0.0), res.get("mfma_busy_lifetime", 1.0)))
+        assert lo - 0.05 <= res["mfma_busy"] <= hi + 0.05, res
+        assert res["met"] == (res["mfma_busy"] >= 0.70)

@@ -74,6 +74,35 @@ def test_dense_oracle_matches_reference_at_bench_size():
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_dense_oracle_matches_reference_at_vitl14_widths():
+    """ViT-L/14 (BASELINE configs[3]): the oracle against the reference's OWN CustomCLIP run at ViT-L/14 widths
+    (tools/make_golden_vitl14_ref.py: trainers/rpo.py's forward and autograd, its four ViT-B/16 dimension literals
+    supplied from outside the module) -- 2 + 2 layers, batch 2: eval logits, loss, both gradients and the prompt rows
+    after every block of both towers (width 1024 / 16 heads / 281 tokens, width 768 / 12 heads)."""
+    import os
+    from helpers import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ref_vitl14_d2_k24_b2.npz")))
+    cfg = vit_l14(layers_v=2, layers_t=2, K=24)
+    toks = synth.oxford_pets_base_tokens()
+    sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
+    assert synth.state_dict_checksum(sd) == g["weights_crc"].item().decode()
+    tp, ip = synth.prompts(cfg, sd, seed=7)
+    m = rpo_oracle.OracleRPO(sd, toks, cfg.K, cfg.patch)
+    m.set_prompts(tp, ip)
+    image, label = synth.images(cfg, 2), synth.labels(cfg, 2)
+    assert np.array_equal(label, g["label"])
+    with torch.no_grad():
+        _, trows = m.text_tower(m.text_prompt, return_rows=True)
+        _, irows = m.image_tower(torch.from_numpy(image), m.img_prompt, return_rows=True)
+    np.testing.assert_allclose(torch.stack(trows).numpy()[:, :4], g["text_rows"], atol=3e-5)
+    np.testing.assert_allclose(torch.stack(irows).numpy(), g["img_rows"], atol=3e-5)
+    out, gt, gi = m.loss_and_grads(image, label)
+    np.testing.assert_allclose(out.logits.detach().numpy(), g["logits"], atol=3e-5, rtol=0)
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-5
+    for mine, ref in ((gt.numpy(), g["g_text"]), (gi.numpy(), g["g_img"])):
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_prompt_rows_per_block():
     g = load_golden("d2_k8_b3")
     m, image, label = oracle_for("d2_k8_b3")

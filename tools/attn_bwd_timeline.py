@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """In-kernel phase timeline of rpo_attn_readonly_bwd_proj / rpo_attn_readonly_bwd (debug build, -DRPO_TIMELINE)."""
-import ctypes as C, os, sys
+import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from rpo_amd import _lib, ops
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
+if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
+    # one recipe for the -DRPO_TIMELINE library (tools/build_debug.sh: EVERY translation unit the ABI needs); compiler output
+    # goes to a log next to the library, never into the timeline this script prints
+    os.makedirs(os.path.dirname(dbg), exist_ok=True)
+    with open(dbg + ".log", "w") as log:
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_debug.sh")], stdout=log, stderr=log)
 lib = _lib.load(dbg); _lib._lib = lib
 lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")

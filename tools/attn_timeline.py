@@ -6,10 +6,12 @@ sys.path.insert(0, ROOT)
 import torch
 from rpo_amd import _lib, ops
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
-src = [os.path.join(ROOT, "rpo_amd", "csrc", f) for f in ("gemm.hip", "norm.hip", "attn_image.hip", "attn_text.hip", "misc.hip")]
-os.makedirs(os.path.dirname(dbg), exist_ok=True)
 if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRPO_TIMELINE", "-fgpu-rdc", *src, "-o", dbg])
+    # one recipe for the -DRPO_TIMELINE library (tools/build_debug.sh: EVERY translation unit the ABI needs); compiler output
+    # goes to a log next to the library, never into the timeline this script prints
+    os.makedirs(os.path.dirname(dbg), exist_ok=True)
+    with open(dbg + ".log", "w") as log:
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_debug.sh")], stdout=log, stderr=log)
 lib = _lib.load(dbg); _lib._lib = lib
 lib.rpo_debug_set_timeline.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")

@@ -6,6 +6,23 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/profiles_raw
 rm -rf $O; mkdir -p $O
+FAILED=""
+# keep OUT TIMEOUT cmd...: stdout+stderr of the tool land in $O/OUT only when it exited 0 and printed no Python traceback;
+# otherwise the output goes to $O/failed/OUT, NO file is left for tools/summarize_profiles.py to commit, and the script
+# exits non-zero at the end (round 4 committed two crash logs as "timelines")
+keep() {
+  local out=$1 to=$2; shift 2
+  mkdir -p $O/failed
+  timeout -k 5 $to "$@" > $O/failed/$out 2>&1
+  local rc=$?
+  if [ $rc -eq 0 ] && ! grep -q "Traceback (most recent call last)" $O/failed/$out; then
+    grep -v "amdgpu.ids" $O/failed/$out > $O/$out; rm -f $O/failed/$out
+  else
+    echo "FAILED ($rc): $out" >&2; FAILED="$FAILED $out"
+  fi
+}
+# the -DRPO_TIMELINE library once, compiler output in its own log (the timeline tools load it)
+bash tools/build_debug.sh > $O/build_debug.log 2>&1 || { echo "FAILED: build_debug.sh" >&2; FAILED="$FAILED build_debug"; }
 timeout 300 python bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-precision > $O/bench_traced.json 2> $O/trace.err
 for shape in qkv out_proj c_fc c_proj; do
@@ -32,13 +49,16 @@ timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench
 # the sibling trainers at the reference's own defaults (CoOp: batch 32, n_ctx 16; CoCoOp: batch 1, n_ctx 4), graph-captured steps
 timeout 300 python bench.py --trainer coop --steps 30 --warmup 5 --no-precision > $O/bench_coop.json 2>> $O/bench.err
 timeout 300 python bench.py --trainer cocoop --steps 30 --warmup 5 --no-precision > $O/bench_cocoop.json 2>> $O/bench.err
-timeout 200 python tools/attn_timeline.py 8 16 32 2>&1 | grep -v amdgpu.ids > $O/attn_timeline.txt
-timeout 200 python tools/gemm_timeline.py > $O/gemm_timeline.txt 2>&1
-timeout 100 python tools/probe_graph_launch.py > $O/graph_phases.txt 2>&1
-[ -z "${QUICK:-}" ] && timeout 300 python tools/probe_cu_mask.py 2>&1 | grep -v amdgpu.ids > $O/cu_mask_probe.txt
-timeout 100 python tools/probe_per_layer.py > $O/per_layer_probe.txt 2>&1
-[ -z "${QUICK:-}" ] && BENCH_CFGS=2,3,7,8,10 timeout 200 python tools/bench_gemm.py > $O/bench_gemm.txt 2>&1
-[ -z "${QUICK:-}" ] && [ -x tools/build/ubench_dma ] && timeout 100 tools/build/ubench_dma > $O/ubench_dma.txt 2>&1
+keep attn_timeline.txt 200 python tools/attn_timeline.py 8 16 32
+keep gemm_timeline.txt 200 python tools/gemm_timeline.py
+keep gemm_ws_timeline.txt 200 python tools/gemm_ws_timeline.py
+keep graph_phases.txt 100 python tools/probe_graph_launch.py
+[ -z "${QUICK:-}" ] && keep cu_mask_probe.txt 300 python tools/probe_cu_mask.py
+keep per_layer_probe.txt 100 python tools/probe_per_layer.py
+[ -z "${QUICK:-}" ] && BENCH_CFGS=2,3,7,8,10 keep bench_gemm.txt 200 python tools/bench_gemm.py
+keep bench_gemm_ws.txt 300 python tools/bench_gemm_ws.py
+[ -z "${QUICK:-}" ] && [ -x tools/build/ubench_dma ] && keep ubench_dma.txt 100 tools/build/ubench_dma
 # the image tower as P part-batches on P streams (round 3: does de-phasing the one-round kernels help?)
-timeout 200 python tools/probe_half_batch.py 32 1 2 4 2>&1 | grep -v amdgpu.ids > $O/half_batch_probe.txt
+[ -z "${QUICK:-}" ] && keep half_batch_probe.txt 200 python tools/probe_half_batch.py 32 1 2 4
 ls $O
+if [ -n "$FAILED" ]; then echo "collect_profiles: FAILED:$FAILED (outputs under $O/failed/, nothing of them will be summarised)" >&2; exit 1; fi

@@ -16,6 +16,9 @@ from rpo_amd._lib import EPI_BIAS, EPI_BIAS_RESID, EPI_NONE, EPI_QGELU_BWD
 
 dbg = os.path.join(ROOT, "rpo_amd", "build", "librpo_hip_dbg.so")
 if not os.path.exists(dbg) or os.environ.get("RPO_REBUILD_DBG"):
+    # one recipe for the -DRPO_TIMELINE library (tools/build_debug.sh: EVERY translation unit the ABI needs); compiler output
+    # goes to a log next to the library, never into the timeline this script prints
+    os.makedirs(os.path.dirname(dbg), exist_ok=True)
     with open(dbg + ".log", "w") as log:
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_debug.sh")], stdout=log, stderr=log)
 lib = _lib.load(dbg)

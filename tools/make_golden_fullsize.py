@@ -9,11 +9,7 @@ on the bench's own shapes so that the model-level comparison goes through the on
   ref_full_k24_b32    12 layers, K = 24, B = 32 (BASELINE.json configs[1]): eval logits, loss, both gradients, the
                       prompts after 1 and 2 SGD steps (explicit lr / momentum / weight decay) and the two losses
   ref_full_k{4,8,16,48}_b32   configs[4], the K sweep: eval logits, loss, both gradients
-  oracle_vitl14_k24_b16       configs[3]: ViT-L/14, 24 + 12 layers, B = 16.  The reference CANNOT run this
-                      (SURVEY.md finding 7: no ViT-L/14 in _MODELS, d_v = 768 / 14 x 14 / 8 text heads / 512 embed are
-                      hard-coded in trainers/rpo.py:52,142,154,185), so this one fixture comes from the repo's own
-                      dimension-generic dense oracle (oracle/rpo_oracle.py, itself pinned to the reference on ViT-B/16)
-                      and says so in the manifest ("source": "oracle").
+  (configs[3], ViT-L/14, 24 + 12 layers, B = 16: ref_full_vitl14_k24_b16 from tools/make_golden_vitl14_ref.py)
 
 Inputs are regenerated from seeds on the GPU box (rpo_amd.synth); only outputs are stored (~0.3 MB).
 Runs in the build container only: ~10 s per reference step on 8 cores.
@@ -33,7 +29,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 
 from rpo_amd import synth  # noqa: E402
-from rpo_amd.config import OXFORD_PETS_BASE_CLASSES, vit_b16, vit_l14  # noqa: E402
+from rpo_amd.config import OXFORD_PETS_BASE_CLASSES, vit_b16  # noqa: E402
 
 import make_golden as mg  # noqa: E402  (the reference harness: stubs, model builder, one train/eval pass)
 
@@ -92,25 +88,8 @@ def main() -> None:
         print(tag, manifest[tag], "|logits|max", float(logits.abs().max()), flush=True)
         del model
 
-    tag = "vitl14_k24_b16"
-    if not only or tag in only:
-        from oracle.rpo_oracle import OracleRPO
-        t0 = time.time()
-        cfg = vit_l14(K=24)
-        sd = synth.clip_state_dict(cfg, seed=0, token_rows=np.unique(toks).tolist() + [49407])
-        tp, ip = synth.prompts(cfg, sd, seed=7)
-        o = OracleRPO(sd, toks, cfg.K, cfg.patch)
-        o.set_prompts(tp, ip)
-        image, label = synth.images(cfg, 16), synth.labels(cfg, 16)
-        out, gt, gi = o.loss_and_grads(image, label)
-        path = os.path.join(out_dir, f"oracle_{tag}.npz")
-        np.savez_compressed(path, logits=out.logits.detach().numpy(), loss=np.float32(out.loss.item()),
-                            g_text=gt.numpy(), g_img=gi.numpy(), label=label,
-                            weights_crc=np.bytes_(synth.state_dict_checksum(sd)))
-        manifest[tag] = dict(source="oracle", why="the reference cannot run ViT-L/14 (SURVEY.md finding 7)",
-                             model="ViT-L/14", depth=24, K=24, B=16, loss=float(out.loss),
-                             bytes=os.path.getsize(path), seconds=round(time.time() - t0, 1))
-        print(tag, manifest[tag], flush=True)
+    # (configs[3], ViT-L/14: tools/make_golden_vitl14_ref.py -- the reference's own CustomCLIP at ViT-L/14 widths;
+    #  until round 5 that fixture came from the oracle)
 
     old = {}
     if os.path.exists(manifest_path):
