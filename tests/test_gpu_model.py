@@ -565,7 +565,7 @@ def test_full_size_sgd_steps_match_reference(act, tol):
 
 # bounds on the LEARNED PROMPTS after the whole run (max abs difference to the reference's, per tensor): the north star's
 # 1e-3 for the fp32 mode; the 16-bit modes' are what was measured on the GPU (printed by the test) with head-room
-TRAJ_TOL = {torch.float32: 1e-3, torch.float16: 2e-3, torch.bfloat16: 1e-2}
+TRAJ_TOL = {torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 5e-3}   # measured: 2.3e-7 / 1.1e-4 / 1.4e-3
 
 
 @pytest.mark.parametrize("act", [torch.float32, torch.float16, torch.bfloat16], ids=lambda v: str(v).replace("torch.", ""))
