@@ -223,6 +223,13 @@ class Engine:
         self.text_proj_t, self.text_proj = self._act(tp.t()), self._act(tp)
         for w in (self.img_proj_t, self.img_proj, self.text_proj_t, self.text_proj):
             self._ws_reg(w)
+        # small batches (config 1: batch 4): the WHOLE image forward is a small-M problem -- B x (N + K) < 2048 rows, no
+        # one-round geometry -- so every block's forward weights get a packed twin too (RPO_WS_SMALL=0: not).  B x (N + K) < 1024.
+        self.ws_small = (self.use_ws and self.max_batch * (cfg.n_frozen + cfg.K) < 1024 and os.environ.get("RPO_WS_SMALL", "1") != "0")
+        if self.ws_small:
+            for blk in self.vis:
+                for w in (blk.w_in, blk.w_in_ln, blk.w_out, blk.w_fc, blk.w_fc_ln, blk.w_proj):
+                    self._ws_reg(w)
         # make_prompts (trainers/rpo.py:135-136): tok_emb[ids] + pos, kept for the frozen tokens only
         tx = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][None]
         self.text_x_frozen = self._f32(tx[:, :self.Lmax].reshape(cfg.n_cls * self.Lmax, cfg.d_t))
@@ -421,10 +428,18 @@ class Engine:
         # profiles/r04_ab_split_k48.txt) -- the four extra 1536-row launches per block (~10 us each) cost more than the
         # one-round kernels save on the frozen rows.
         split = self._split_rows(B)
+        # small batches: every "wide" launch is a small-M GEMM and goes to rpo_gemm_ws (no row units, 64-column statistics)
+        # (measured, tools/ab_env.py --extra "--batch B": B = 4 step 1.509 vs 1.554 ms, B = 8 1.958 vs 1.723 ms -- from
+        #  1024 rows on the 64x128 / 128x128 tiles win; the unmasked towers (full_last: zero-shot / CoOp) keep rpo_gemm_nt)
+        small = self.ws_small and R < 1024 and not split and not full_last
+        if small:
+            units = None
         Mw = Rf if split else R                                       # rows of the whole-batch ("wide") launches
         if split:
             units = (N, 0, Rf)
         u_out, u_proj = (units if which == "all" else None), (units if which in ("all", "c_proj") else None)
+        if small:
+            u_out = u_proj = None
         grps = self._stats_group.get((B, split))
         if grps is None:
             grps = self._stats_group[(B, split)] = ((ops.gemm_stats_group(Mw, dv, dv, self.act, u_out),
@@ -495,6 +510,10 @@ class Engine:
                         ops.gemm_nt(h[:Rf], w_in, qkv[:Rf], epi_in, bias=b_in, **lnk(0, Rf, 0, 3 * dv), prefetch=pf_of("in_", l))
                     # K/V of prompt rows are never read (visual mask, rpo.py:154-156): their q alone
                     ops.gemm_nt(h[Rf:], w_in[:dv], qkv[Rf:, :dv], epi_in, bias=b_in[:dv], **lnk(Rf, R, 0, dv, own=True))
+                elif small:
+                    # (rpo_gemm_ws has no tile skipping: the K / V of the few prompt rows are computed and never read)
+                    with self._timed("in_proj"):
+                        self._gemm(h, w_in, qkv, epi_in, bias=b_in, **lnk(0, R, 0, 3 * dv), prefetch=pf_of("in_", l))
                 else:
                     # K/V of prompt rows are never read (visual mask, rpo.py:154-156): skip those tiles
                     with self._timed("in_proj"):
@@ -530,7 +549,7 @@ class Engine:
                 if hl:
                     prod.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)             # (h_lo None: the hi half alone)
                 # (prompt rows alone -- the last block, the split mode -- go to rpo_gemm_ws where the weight has a packed twin)
-                gemm = ops.gemm_nt if wide else self._gemm
+                gemm = ops.gemm_nt if (wide and not small) else self._gemm
                 with timed("out_proj"):
                     gemm(att[lo:hi], blk.w_out, xm[lo:hi], EPI_BIAS_RESID, bias=blk.b_out, row_units=un_o,
                          **res_o, **prod, prefetch=pf_of("out", l) if wide else None)
@@ -541,7 +560,7 @@ class Engine:
                     prod_p.update(out_lo=None if h_lo is None else h_lo[:hi], c_row0=Rf)
                 proj_kw = dict(a=g[lo:hi], w=blk.w_proj, out=xo[lo:hi], epilogue=EPI_BIAS_RESID, bias=blk.b_proj, row_units=un_p,
                                **res_p, **prod_p, prefetch=pf_of("proj", l) if wide else None)
-                if not wide:                  # (64-column statistics either way; no row units)
+                if not wide or small:         # (64-column statistics either way; no row units)
                     proj_kw.pop("row_units"); proj_kw.pop("ln_group", None)
                 # EXPERIMENT (round 4, RPO_MLP_FUSED=1 / =safe): c_fc -> c_proj of a whole-batch block as ONE launch
                 # (rpo_mlp_fused: the 8 workgroups of an image hand g over through their XCD's L2 at a counter)
@@ -566,7 +585,7 @@ class Engine:
                         gemm(h[lo:hi], blk.w_fc, g[lo:hi], EPI_BIAS_QGELU, bias=blk.b_fc,
                              aux=aux, aux_row0=aux_row0, row_units=un)
                 with timed("c_proj"):
-                    if wide:
+                    if wide and not small:
                         ops.gemm_nt(**proj_kw)
                     else:
                         pk = dict(proj_kw)
