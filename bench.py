@@ -539,6 +539,8 @@ def main() -> None:
         # a fixed name in the world-writable temp dir could be pre-planted as a symlink (advisor finding, round 3)
         import tempfile
         shared_dir = sync.broadcast_object(tempfile.mkdtemp(prefix="rpo_amd_weights_") if sync.rank == 0 else None)
+        if sync.local_writer:                        # (a multi-node launch: the name is rank 0's, every NODE's writer makes
+            os.makedirs(shared_dir, mode=0o700, exist_ok=True)    # its own private directory of that name -- advisor, round 4)
         shared = os.path.join(shared_dir, "weights.npy")
         sd = synth.clip_state_dict_shared(cfg, 0, token_rows, shared, writer=sync.local_writer, barrier=sync.barrier)
     else:

@@ -105,13 +105,6 @@ SIGNATURES = {
     "rpo_gemm_ws": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "rpo_gemm_ws_pack": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "rpo_gemm_ws_ok": (c_i32, [C.POINTER(GemmArgs)]),
-    "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
-    "rpo_mlp_fused": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp, c_i32, c_vp]),
-    "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),
-    "rpo_attn_bwd_proj_pair": (c_i32, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_i32, c_vp]),
-    "rpo_chain_state_bytes": (C.c_size_t, []),
-    "rpo_chain_bwd": (c_i32, [C.POINTER(ChainBwdArgs), c_vp]),
-    "rpo_chain_bwd_ok": (c_i32, [C.POINTER(ChainBwdArgs)]),
     "rpo_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "rpo_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                   c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i64, c_vp]),
@@ -154,6 +147,18 @@ SIGNATURES = {
                                      C.c_size_t, c_vp]),
 }
 
+# include/rpo_amd_experimental.h: bound only from the -DRPO_EXPERIMENTAL build of the library (RPO_EXPERIMENTAL=1)
+EXPERIMENTAL_SIGNATURES = {
+    "rpo_gemm_nt_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
+    "rpo_mlp_fused": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp, c_i32, c_vp]),
+    "rpo_layernorm_bwd_pair": (c_i32, [C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_vp]),
+    "rpo_attn_bwd_proj_pair": (c_i32, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_i32, c_vp]),
+    "rpo_chain_state_bytes": (C.c_size_t, []),
+    "rpo_chain_bwd": (c_i32, [C.POINTER(ChainBwdArgs), c_vp]),
+    "rpo_chain_bwd_ok": (c_i32, [C.POINTER(ChainBwdArgs)]),
+}
+EXPERIMENTAL = os.environ.get("RPO_EXPERIMENTAL") == "1"
+
 _lib = None
 
 
@@ -166,7 +171,11 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("RPO_HIP_LIB") or LIB_PATH      # RPO_HIP_LIB: A/B a variant build (tools/)
+    p = path or os.environ.get("RPO_HIP_LIB")                  # RPO_HIP_LIB: A/B a variant build (tools/)
+    if p is None and EXPERIMENTAL:                             # the experiments' library, built on first use
+        from .build import build_library
+        p = build_library(experimental=True)
+    p = p or LIB_PATH
     # PyTorch-ROCm bundles its own libamdhip64.so.7; librpo_hip.so must bind to THAT runtime
     # (same SONAME as /opt/rocm's) or the two would hold separate device contexts and torch's
     # pointers/streams would be foreign to our kernels.  Importing torch first makes the dynamic
@@ -187,8 +196,22 @@ def load(path: str | None = None):
             raise RPOLibraryError(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():   # present only in the -DRPO_EXPERIMENTAL build
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if path is None:
         _lib = lib
+    return lib
+
+
+def experimental():
+    """The library with the experiments' entry points (include/rpo_amd_experimental.h), or an error that says how to get it."""
+    lib = load()
+    if not hasattr(lib, "rpo_chain_bwd"):
+        raise RPOLibraryError("this entry point belongs to the measured-slower experiments of rounds 3 / 4: set "
+                              "RPO_EXPERIMENTAL=1 (loads rpo_amd/build/librpo_hip_exp.so, built with -DRPO_EXPERIMENTAL)")
     return lib
 
 

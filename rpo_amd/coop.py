@@ -81,7 +81,8 @@ def _init_ctx(cfg: RPOConfig, n_cls: int, n_ctx: int, csc: bool, ctx, ctx_init, 
         if ci.ndim == 1:                                                     # token ids of the words
             ci = np.asarray(token_embedding)[ci.astype(np.int64)]
         assert ci.shape == (n_ctx, cfg.d_t), "ctx_init: n_ctx word embeddings (or their token ids)"
-        assert not csc, "trainers/coop.py:72-80: CTX_INIT gives one generic context"
+        # (with CSC the reference takes this branch too and silently trains ONE generic context, trainers/coop.py:72-80
+        #  before :84; callers see it in coop_ctx's shape)
         return ci.astype(np.float32)
     shape = (n_cls, n_ctx, cfg.d_t) if csc else (n_ctx, cfg.d_t)
     return torch.empty(*shape).normal_(std=0.02).numpy()
@@ -99,6 +100,8 @@ class CoOpCustomCLIP:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])     # one (unused) RPO prompt row per image
         self.cfg = cfg
         self.engine = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        if ctx is None and ctx_init is not None:
+            csc = False                      # CTX_INIT wins over CSC, as in the reference (trainers/coop.py:72-80 vs :84)
         with torch.cuda.device(self.engine.dev):
             self.engine.coop_setup(n_ctx, csc=csc, class_token_position=class_token_position)
             # (random: the reference's own draw from torch's global generator, so a seeded run starts from its vectors)
@@ -205,18 +208,33 @@ class CoOp:
             for name, p in params:
                 if name in sd:
                     p.copy_(torch.as_tensor(sd[name]).to(p.dtype).reshape(p.shape))
+        # weights only, as the reference's load_model (trainers/coop.py:283-325: load_state_dict(strict=False) and nothing
+        # else): optimiser state, epoch and learning rate stay what they were -- loading a finished model-best file and
+        # training on must not start at the cosine's last rate with stale momentum (advisor, round 4).  Resuming a run is
+        # `resume_model` below (Dassl's resume_model_if_exist).
+        self._ckpt = ck
+        self._graph = None
+
+    def resume_model(self, directory: str, epoch: Optional[int] = None) -> int:
+        """Dassl's `resume_model_if_exist` for this trainer: `load_model` plus the optimiser's momentum buffers, the epoch
+        and the learning rate of the checkpoint.  Returns the epoch to continue from.  A checkpoint whose momentum does
+        not match the trained tensors (another n_ctx / CSC setting) is refused rather than half-applied."""
+        self.load_model(directory, epoch)
+        ck = self._ckpt
+        params = list(self.model.prompt_learner.named_parameters())
         st = (ck.get("optimizer") or {}).get("state") or {}
-        try:
+        if st:
             bufs = [st[i]["momentum_buffer"] for i in range(len(params))]
             flat = torch.cat([torch.as_tensor(b).reshape(-1).float() for b in bufs])
-            if flat.numel() == self.engine.coop_moms.numel():
-                self.engine.coop_moms.copy_(flat)
-                self._steps = max(1, int(ck.get("steps", 1)))
-        except (KeyError, TypeError, RuntimeError):
-            pass                                                     # a checkpoint without momentum: start it from zero
+            if flat.numel() != self.engine.coop_moms.numel():
+                raise ValueError(f"checkpoint momentum has {flat.numel()} elements, the trainer {self.engine.coop_moms.numel()}: "
+                                 "it was written with other context settings")
+            self.engine.coop_moms.copy_(flat)
+            self._steps = max(1, int(ck.get("steps", 1)))
         self.epoch = int(ck.get("epoch", 0))
         self.lr = lr_at_epoch(self.optim_cfg, self.epoch)
         self._graph = None
+        return self.epoch
 
     def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
         """One optimisation step, nothing synchronised; returns the device loss scalar.  With use_graph the ~250 launches

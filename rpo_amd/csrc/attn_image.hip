@@ -1218,6 +1218,7 @@ extern "C" int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const
 
 // rpo_attn_readonly_bwd_proj for one or two problems in ONE launch, each with optional per-group key counts
 // (include/rpo_amd.h: rpo_attn_bwd_args).  a1 == NULL: one problem.
+#ifdef RPO_EXPERIMENTAL   // measured-slower experiment: include/rpo_amd_experimental.h
 extern "C" int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_attn_bwd_args* a1, int dtype, void* stream) {
   if (a0 == nullptr) return RPO_E_BADARG;
   if (dtype != RPO_BF16 && dtype != RPO_F16) return RPO_E_DTYPE;
@@ -1227,4 +1228,5 @@ extern "C" int rpo_attn_bwd_proj_pair(const rpo_attn_bwd_args* a0, const rpo_att
   if (dtype == RPO_BF16) return dispatch_bwd_proj_args<bf16_t>(a0, a1, s);
   return dispatch_bwd_proj_args<f16_t>(a0, a1, s);
 }
+#endif  // RPO_EXPERIMENTAL
 #endif  // RPO_DEVICE_ONLY

@@ -5,6 +5,9 @@
 #include <stdint.h>
 
 #include "../../include/rpo_amd.h"
+// Argument structs of the experiments are also what some default kernels take internally, so the DECLARATIONS are always
+// visible to the library's own sources; the entry points are DEFINED only with -DRPO_EXPERIMENTAL.
+#include "../../include/rpo_amd_experimental.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 // raw IEEE binary16 bits (TRAINER.RPO.PREC = fp16 / amp, trainers/rpo.py:247-249): a distinct type, so that templates

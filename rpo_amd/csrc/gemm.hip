@@ -1162,6 +1162,7 @@ extern "C" int rpo_gemm_nt(const rpo_gemm_args* a, void* stream) {
   return dispatch_f32out<float>(epi, p, s);
 }
 
+#ifdef RPO_EXPERIMENTAL   // measured-slower experiments (include/rpo_amd_experimental.h): rpo_mlp_fused, rpo_gemm_nt_pair
 // c_fc -> c_proj of an image block in ONE launch (gemm_mlp.inc; include/rpo_amd.h).  RPO_E_SHAPE where it does not apply
 // (the caller then issues the two rpo_gemm_nt calls it stands for): both GEMMs must be the row-unit, one-round forms --
 // 224x384 tiles with a QuickGELU epilogue feeding 224x96 split-k tiles with the residual epilogue, the same row units, 8
@@ -1262,3 +1263,4 @@ extern "C" int rpo_gemm_nt_pair(const rpo_gemm_args* a0, const rpo_gemm_args* a1
   if (a0->in_dtype == RPO_F16) return dispatch_pair<f16_t>(a0->epilogue, out16, g, tiles1, g.p[0].split_k, s);
   return dispatch_pair<bf16_t>(a0->epilogue, out16, g, tiles1, g.p[0].split_k, s);
 }
+#endif  // RPO_EXPERIMENTAL

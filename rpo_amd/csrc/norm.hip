@@ -322,6 +322,7 @@ static int ln_bwd_check(const void* dy, int dy_dtype, int64_t lddy, const float*
   return 0;
 }
 
+#ifdef RPO_EXPERIMENTAL   // measured-slower experiment: include/rpo_amd_experimental.h
 extern "C" int rpo_layernorm_bwd_pair(const rpo_ln_bwd_args* a0, const rpo_ln_bwd_args* a1, void* stream) {
   if (!a0 || !a1) return RPO_E_BADARG;
   LnBwdPair g;
@@ -352,6 +353,7 @@ extern "C" int rpo_layernorm_bwd_pair(const rpo_ln_bwd_args* a0, const rpo_ln_bw
 #undef RPO_LN_PAIR_
   return rpo_launch_status();
 }
+#endif  // RPO_EXPERIMENTAL
 
 extern "C" int rpo_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const float* x, int64_t ldx,
                                  const float* gamma, const float* dres, int64_t lddres, float* dx,

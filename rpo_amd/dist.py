@@ -39,6 +39,7 @@ class GradSync:
         # Test hooks for boxes with fewer GPUs than ranks: RPO_ALL_RANKS_ON_GPU0=1 puts every rank on cuda:0 and
         # RPO_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the N-rank control flow
         # (sharding, collectives, barriers, max-over-ranks timing) is then exercised end to end on one GPU.
+        self.host_rank = self.local_rank            # the launcher's LOCAL_RANK: this process's share of the HOST (pin_host)
         if os.environ.get("RPO_ALL_RANKS_ON_GPU0") == "1":
             self.local_rank = 0
         # RPO_FORCE_DIST=1 runs the collective path even with one rank (exercises RCCL init / all-reduce /
@@ -61,6 +62,10 @@ class GradSync:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    @property
+    def backend(self) -> str:
+        return dist.get_backend() if (self.enabled and dist.is_initialized()) else "none"
 
     # ---- host side of an N-rank node: SURVEY 8e names host jitter as THE scaling risk (each rank replays five graphs and
     # one collective every ~3 ms), so under a launcher every rank pins itself to the cores of its GPU's NUMA node and
@@ -91,14 +96,14 @@ class GradSync:
                 same = [r for r in peers if _gpu_numa_node(r) == node] or [self.local_rank]
                 mine = sorted(want & set(allowed))
                 if mine:
-                    k = same.index(self.local_rank) if self.local_rank in same else 0
+                    k = same.index(self.host_rank) if self.host_rank in same else 0
                     per = max(1, len(mine) // len(same))
                     cpus, how = mine[k * per:(k + 1) * per] or mine, f"numa node {node}"
         except Exception:
             cpus = None
         if not cpus and local_world > 1:
             per = max(1, len(allowed) // local_world)
-            cpus, how = allowed[self.local_rank * per:(self.local_rank + 1) * per] or allowed, "even share of the allowed cpus"
+            cpus, how = allowed[self.host_rank * per:(self.host_rank + 1) * per] or allowed, "even share of the allowed cpus"
         if cpus:
             try:
                 os.sched_setaffinity(0, cpus)

@@ -36,6 +36,14 @@ import contextlib
 
 SCALE = 1.0 / math.sqrt(64.0)
 _NO_PROBE = contextlib.nullcontext()
+
+
+def _xenv(name: str, default: str = "0") -> str:
+    """Switch of a measured-slower EXPERIMENT: read only when RPO_EXPERIMENTAL=1 -- which also
+    selects the -DRPO_EXPERIMENTAL build of the library (rpo_amd/_lib.py) -- otherwise the default.  The default train
+    step, the eval path and the sibling trainers never take these branches."""
+    from ._lib import EXPERIMENTAL
+    return os.environ.get(name, default) if EXPERIMENTAL else default
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
 # d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.  Tuned at step level:
 # 4, 6, 8 slabs for c_fc and 3, 4 for the q-projection were slower (more slabs cost output bandwidth).
@@ -256,7 +264,7 @@ class Engine:
         # must run with RPO_NO_HILO=1 (tools/probe_alias_buffers.py does).
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
-        self.mlp_counters = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # rpo_mlp_fused: one per row unit + give-ups, never reset
+        self.mlp_counters = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # rpo_mlp_fused (experiment): one per row unit + give-ups, never reset
         self.h = a(R, dv)
         self.h_lo = a(R, dv)                         # lo half of the residual stream (hi / lo mode: _image_forward)
         self.ln_stats = f32(R, dv // 64, 2)          # per-row partial LayerNorm statistics of the tensor self.h copies
@@ -275,9 +283,10 @@ class Engine:
         self.dy_v = f32(max(SPLIT_FC, SPLIT_Q, 4), Rp, dv)       # (rpo_gemm_ws splits d c_fc in up to four)
         # the persistent backward chain (rpo_chain_bwd): 4 k-slice slabs, its scratch (one per tower: the two chains run
         # concurrently), optional stage timeline (tools/chain_timeline.py sets it)
-        self.dy4_v = f32(4, Rp, dv)
-        self.chain_state_v = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev)
-        self.chain_state_t = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev)
+        from ._lib import EXPERIMENTAL
+        self.dy4_v = f32(4, Rp, dv) if EXPERIMENTAL else None
+        self.chain_state_v = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev) if EXPERIMENTAL else None
+        self.chain_state_t = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev) if EXPERIMENTAL else None
         self.chain_timeline = None
         self.dxa_v, self.dxb_v = f32(Rp, dv), f32(Rp, dv)
         self.dxc_v = a(Rp, dv)
@@ -299,7 +308,7 @@ class Engine:
         self.d_text_f_a = a(Rt, e)
         self.ln_stats_t = f32(Rt, dt // 64, 2)
         self.dy_t = f32(max(SPLIT_FC, SPLIT_Q, 4), Rt, dt)
-        self.dy4_t = f32(4, Rt, dt)
+        self.dy4_t = f32(4, Rt, dt) if EXPERIMENTAL else None
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
         self.du_t = a(Rt, 4 * dt)
@@ -489,7 +498,7 @@ class Engine:
             return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
                     "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
         no_probe = lambda name: _NO_PROBE
-        mlp_fused = os.environ.get("RPO_MLP_FUSED", "0")
+        mlp_fused = _xenv("RPO_MLP_FUSED", "0")
         mlp_fused = mlp_fused if mlp_fused in ("1", "safe") and self.act != torch.float32 else ""
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
@@ -598,7 +607,7 @@ class Engine:
         16-bit modes with the LayerNorm fold, when the one-round row-unit kernels take an image's N frozen rows but not
         its N + K rows (RPO_SPLIT=1), or wherever they take the frozen rows (RPO_SPLIT=force: the test's switch)."""
         cfg = self.cfg
-        mode = os.environ.get("RPO_SPLIT", "0")          # "1": where the whole rows do not fit; "force": wherever the frozen rows do
+        mode = _xenv("RPO_SPLIT", "0")          # "1": where the whole rows do not fit; "force": wherever the frozen rows do
         if self.act == torch.float32 or not self.fold_ln or mode not in ("1", "force") or cfg.K == 0:
             return False
         key = ("split", B)
@@ -678,7 +687,7 @@ class Engine:
         # 16-bit modes, K <= 64, d = 512 / 768 / 1024: the d out-proj GEMM runs inside the attention backward kernel
         # (round 4: d = 1024 -- ViT-L/14 -- and K in (32, 64] -- one workgroup per 32-query tile; A/B: RPO_BWD_FOLD_R3=1
         # restores the round-3 coverage)
-        r3 = os.environ.get("RPO_BWD_FOLD_R3") == "1"
+        r3 = _xenv("RPO_BWD_FOLD_R3") == "1"
         fold_out = (self.act != torch.float32 and K <= (32 if r3 else 64) and dv in ((512, 768) if r3 else (512, 768, 1024))
                     and os.environ.get("RPO_NO_BWD_FOLD") != "1")
 
@@ -691,7 +700,7 @@ class Engine:
                 ops.attn_readonly_bwd(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da, dq,
                                       nb, H, N, K, SCALE)
 
-        if self.chain_ok("v", nb):
+        if nb == B and self.chain_ok("v", nb):      # (never for a part of the batch: one scratch buffer, one resident chain per tower)
             # the 6 x layers stages as ONE persistent launch (rpo_chain_bwd, csrc/chain.hip): A/B switch RPO_CHAIN=0
             layers = [dict(w_proj_t=b.w_proj_t, w_fc_t=b.w_fc_t, w_out_t=b.w_out_t, w_q_t=b.w_q_t, aux=self.u[l][r0:r1],
                            x_ln2=self.xm[l][Rf + r0:Rf + r1], x_ln1=self.x[l][Rf + r0:Rf + r1], ln2_w=b.ln2_w, ln1_w=b.ln1_w,
@@ -715,14 +724,14 @@ class Engine:
         launch-per-stage chain -- image tower at B = 32: 1.10-1.20 ms against 0.77 ms (profiles/r04_chain_*.txt).  A
         stage costs ~5-6 us of drain + counter + poll + first dependent load whether or not a kernel boundary sits in
         it, and one workgroup per CU cannot keep enough LDS-DMA bytes in flight (72 KB ring: ~40 GB/s per CU)."""
-        if self.act == torch.float32 or os.environ.get("RPO_CHAIN") != "1" or os.environ.get("RPO_AUX_F32") == "1":
+        if self.act == torch.float32 or _xenv("RPO_CHAIN") != "1" or os.environ.get("RPO_AUX_F32") == "1":
             return False
         cfg = self.cfg
         if tower == "v":
-            if os.environ.get("RPO_CHAIN_IMAGE", "1") == "0":     # (text tower alone: RPO_CHAIN=1 RPO_CHAIN_TEXT=1 RPO_CHAIN_IMAGE=0)
+            if _xenv("RPO_CHAIN_IMAGE", "1") == "0":     # (text tower alone: RPO_CHAIN=1 RPO_CHAIN_TEXT=1 RPO_CHAIN_IMAGE=0)
                 return False
             return ops.chain_bwd_ok(cfg.layers_v, units, cfg.K, cfg.d_v, cfg.heads_v, cfg.n_frozen, self.act)
-        if os.environ.get("RPO_CHAIN_TEXT", "0") != "1" or self.Lmax > 96:
+        if _xenv("RPO_CHAIN_TEXT", "0") != "1" or self.Lmax > 96:
             return False
         return ops.chain_bwd_ok(cfg.layers_t, units, cfg.K, cfg.d_t, cfg.heads_t, self.Lmax, self.act)
 
@@ -745,7 +754,7 @@ class Engine:
         can = (self.act != torch.float32 and cfg.K <= 32 and cfg.d_v == 768 and cfg.d_t in (512, 768)
                and self.Lmax <= 96 and cfg.n_frozen > 96 and cfg.n_frozen <= 224
                and os.environ.get("RPO_NO_BWD_FOLD") != "1")
-        return can and os.environ.get("RPO_JOINT_BWD") == "1"
+        return can and _xenv("RPO_JOINT_BWD") == "1"
 
     def _joint_backward(self, B: int) -> None:
         """_image_backward + _text_backward with every stage of the two chains in ONE launch (rpo_gemm_nt_pair,
@@ -830,7 +839,7 @@ class Engine:
         # waits for, its kernels' footprint on the CUs is, and the MFMA kernel (250 VGPRs, 66 KB of LDS per workgroup)
         # stands in the image chain's way more than the VALU kernel + a 64x64 GEMM do.
         fold_out = (self.act != torch.float32 and K <= 32 and dt in (512, 768) and self.Lmax <= 96
-                    and os.environ.get("RPO_NO_BWD_FOLD") != "1" and os.environ.get("RPO_TEXT_BWD_FOLD") == "1")
+                    and os.environ.get("RPO_NO_BWD_FOLD") != "1" and _xenv("RPO_TEXT_BWD_FOLD") == "1")
 
         def attn_bwd(l, da, dq):
             kv = self.kv_t[l]

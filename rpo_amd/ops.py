@@ -175,7 +175,7 @@ def gemm_nt_pair(g0: dict, g1: dict) -> None:
     """Two small-M GEMMs of the same kind in ONE launch (rpo_gemm_nt_pair): g0 / g1 are the keyword arguments of
     `gemm_nt` (a, w, out, epilogue, ...) of the two problems."""
     a0, a1 = gemm_args(**g0), gemm_args(**g1)
-    check(_lib.load().rpo_gemm_nt_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_gemm_nt_pair")
+    check(_lib.experimental().rpo_gemm_nt_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_gemm_nt_pair")
 
 
 def mlp_fused(fc: dict, proj: dict, counters: torch.Tensor, safe: bool = False) -> bool:
@@ -184,7 +184,7 @@ def mlp_fused(fc: dict, proj: dict, counters: torch.Tensor, safe: bool = False) 
     issues the two calls."""
     a0, a1 = gemm_args(**fc), gemm_args(**proj)
     assert counters.dtype == torch.int32 and counters.is_contiguous()
-    rc = _lib.load().rpo_mlp_fused(C.byref(a0), C.byref(a1), counters.data_ptr(), int(safe), _stream())
+    rc = _lib.experimental().rpo_mlp_fused(C.byref(a0), C.byref(a1), counters.data_ptr(), int(safe), _stream())
     if rc == -2:                                     # RPO_E_SHAPE
         return False
     check(rc, "rpo_mlp_fused")
@@ -260,7 +260,7 @@ def _ln_bwd_args(dy, x, gamma, dres, dx, dx_cast=None, eps: float = LN_EPS) -> "
 def layernorm_bwd_pair(l0: dict, l1: dict) -> None:
     """Two `layernorm_bwd` problems (keyword arguments dy, x, gamma, dres, dx, dx_cast) in ONE launch."""
     a0, a1 = _ln_bwd_args(**l0), _ln_bwd_args(**l1)
-    check(_lib.load().rpo_layernorm_bwd_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_layernorm_bwd_pair")
+    check(_lib.experimental().rpo_layernorm_bwd_pair(C.byref(a0), C.byref(a1), _stream()), "rpo_layernorm_bwd_pair")
 
 
 def _attn_bwd_args(q_rows, k, v, dx, w_out_t, dq, groups: int, H: int, keys: int, Kp: int, scale: float = 0.125,
@@ -280,7 +280,7 @@ def attn_bwd_proj_pair(p0: dict, p1: Optional[dict] = None) -> None:
     for per-group key counts (the text tower's K / V cache), key_len (int32 [groups]) + key_stride."""
     a0 = _attn_bwd_args(**p0)
     a1 = None if p1 is None else _attn_bwd_args(**p1)
-    check(_lib.load().rpo_attn_bwd_proj_pair(C.byref(a0), None if a1 is None else C.byref(a1),
+    check(_lib.experimental().rpo_attn_bwd_proj_pair(C.byref(a0), None if a1 is None else C.byref(a1),
                                              dtype_code(p0["dq"].dtype), _stream()), "rpo_attn_bwd_proj_pair")
 
 
@@ -355,7 +355,7 @@ def attn_readonly_bwd(q_rows, k, v, da, dq, B: int, H: int, N: int, Kp: int, sca
 
 def chain_state() -> int:
     """bytes of device scratch rpo_chain_bwd needs (counters, placement table)"""
-    return int(_lib.load().rpo_chain_state_bytes())
+    return int(_lib.experimental().rpo_chain_state_bytes())
 
 
 def _chain_args(layers: list, units: int, Kp: int, d: int, H: int, keys: int, dtype: torch.dtype, key_len=None,
@@ -378,7 +378,7 @@ def chain_bwd_ok(layers: int, units: int, Kp: int, d: int, H: int, keys: int, dt
     if dtype == torch.float32:
         return False
     a = _lib.ChainBwdArgs(layers=layers, units=units, Kp=Kp, d=d, H=H, keys=keys, dtype=dtype_code(dtype))
-    return bool(_lib.load().rpo_chain_bwd_ok(C.byref(a)))
+    return bool(_lib.experimental().rpo_chain_bwd_ok(C.byref(a)))
 
 
 def chain_bwd(layers: list, **kw) -> None:
@@ -386,7 +386,7 @@ def chain_bwd(layers: list, **kw) -> None:
     layers: one dict per block (block 0 first) with the tensors of struct rpo_chain_layer; x_ln2 / x_ln1 / q_rows are
     views of the back-propagated rows; dy: fp32 [4, rows, d] slabs."""
     a = _chain_args(layers, **kw)
-    check(_lib.load().rpo_chain_bwd(C.byref(a), _stream()), "rpo_chain_bwd")
+    check(_lib.experimental().rpo_chain_bwd(C.byref(a), _stream()), "rpo_chain_bwd")
 
 
 def text_attn_fwd(q, kc, vc, out, len_i32, n_cls: int, rows: int, Lmax: int, H: int, causal: bool = False,

@@ -23,6 +23,7 @@ from . import ops
 from .config import RPOConfig
 from .custom_clip import CustomCLIP
 from .dist import GradSync
+from .engine import _xenv
 
 
 @dataclass
@@ -152,14 +153,17 @@ class RPO:
         # both backward chains as one chain of paired launches where the kernels allow it (Engine._joint_backward)
         self._joint_bwd = eng.joint_backward_ok(B)
         self._bwd_parts = 1
-        self._split_collective = self.sync.enabled and os.environ.get("RPO_ONE_COLLECTIVE") != "1"
+        # (asynchronous with RCCL only: gloo on device tensors blocks the host until the text backward and the collective
+        #  are done, and the image backward would be launched behind it -- advisor, round 4)
+        self._split_collective = (self.sync.enabled and os.environ.get("RPO_ONE_COLLECTIVE") != "1"
+                                  and self.sync.backend == "nccl")
         if self._joint_bwd:
             self._g_bwd = cap(lambda: eng._joint_backward(B))
         else:
             self._g_text_bwd = cap(eng._text_backward)
             # RPO_BWD_PARTS = P > 1: the image tower's prompt-row chain as P independent chains over B / P images each, on
             # P streams (Engine._image_backward_rows: the rows of different images never meet before the batch sum)
-            P = int(os.environ.get("RPO_BWD_PARTS", "1"))
+            P = int(_xenv("RPO_BWD_PARTS", "1"))
             self._bwd_parts = P if (P > 1 and B % P == 0) else 1
             if self._bwd_parts > 1:
                 per = B // self._bwd_parts
@@ -272,6 +276,12 @@ class RPO:
                               ("grad img_prompt", eng.g_img), ("prompts", eng.params)) if not bool(torch.isfinite(t).all())]
         if bad:
             raise FloatingPointError(f"non-finite values after step {self._steps}: {', '.join(bad)}")
+        # experiments only (RPO_EXPERIMENTAL=1): a bounded spin of a persistent launch that gave up leaves results
+        # undefined, not non-finite -- its give-up words are part of the scan (advisor, round 4)
+        for name, t, idx in (("rpo_chain_bwd (image)", eng.chain_state_v, 0), ("rpo_chain_bwd (text)", eng.chain_state_t, 0),
+                             ("rpo_mlp_fused", eng.mlp_counters if _xenv("RPO_MLP_FUSED") != "0" else None, -1)):
+            if t is not None and int(t[idx]) != 0:
+                raise RuntimeError(f"{name}: a bounded spin gave up in or before step {self._steps}: the results are undefined")
 
     # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
     @torch.no_grad()
