@@ -565,8 +565,11 @@ def main() -> None:
     sync.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(args.steps):
+        th = time.perf_counter()
         loss = tr.step_async(imgs[i % pool], labs[i % pool])
+        host_s += time.perf_counter() - th           # host time spent ENQUEUING the step (replays, events, collectives)
     torch.cuda.synchronize()
     sync.barrier()
     torch.cuda.synchronize()
@@ -615,6 +618,9 @@ def main() -> None:
                    "rank_ms_per_step": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
                                         "all": [round(v, 4) for v in per_rank_ms]},
                    "host": host,
+                   # host-side enqueue time per step on this rank (the device runs ahead of it when it is below ms_per_step)
+                   "host_us_per_step": round(1e6 * host_s / args.steps, 1),
+                   "collectives_in_graph": bool(getattr(tr, "_graph_collectives", False)),
                    "hip_graph": not args.no_graph, "final_loss": round(last_loss, 5)},
         "roofline": {"bound": "mfma",
                      # the stricter figure first: FLOPs the engine really EXECUTES per step (the SURVEY 8d contract

@@ -82,6 +82,9 @@ class RPO:
         self._graph = None
         self._joint_bwd = False
         self._split_collective = False
+        self._graph_collectives = False
+        self._text_ar_in_graph = False
+        self._tail_graphs = {}
         self.best_result = -float("inf")
         self._found_inf = None                       # amp: int32[2] on the device (this step's flag, skipped steps)
         # trainers/rpo.py:287-288 turns on autograd anomaly detection ("nan detector"); there is no autograd graph
@@ -140,6 +143,17 @@ class RPO:
         eng, B = self.engine, self.batch_size
         eng.forward_backward(self._image, self._label)          # eager warm-up: sets kernel attributes,
         torch.cuda.synchronize()                                # builds the text K/V cache
+        # N > 1 without Python in the loop: the two all-reduces and the SGD launch are captured too (RCCL collectives are
+        # capturable once the communicator exists -- one eager all-reduce here creates it), so a step is six graph replays
+        # and a handful of event calls per rank.  Falls back to eager collectives if a capture fails;
+        # RPO_NO_GRAPH_COLLECTIVES=1 keeps them eager.
+        self._graph_collectives = (self.sync.enabled and self.sync.backend == "nccl"
+                                   and os.environ.get("RPO_NO_GRAPH_COLLECTIVES") != "1")
+        if self._graph_collectives:
+            self.sync.all_reduce_sum(eng.grads)                 # (warm-up gradients: the first real step overwrites them)
+            torch.cuda.synchronize()
+        self._tail_graphs = {}
+
         def cap(fn):
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of a data-parallel run may query events while we capture
@@ -160,7 +174,17 @@ class RPO:
         if self._joint_bwd:
             self._g_bwd = cap(lambda: eng._joint_backward(B))
         else:
-            self._g_text_bwd = cap(eng._text_backward)
+            self._text_ar_in_graph = False
+            if self._split_collective and self._graph_collectives:
+                try:                                # text backward + the all-reduce of its gradient as one graph
+                    self._g_text_bwd = cap(lambda: (eng._text_backward(), self.sync.all_reduce_sum(eng.g_text_flat)))
+                    self._text_ar_in_graph = True
+                except Exception as ex:             # noqa: BLE001 -- any capture failure: eager collectives
+                    print(f"[rpo_amd] capturing the collective failed ({type(ex).__name__}: {ex}); collectives stay eager")
+                    self._graph_collectives = False
+                    torch.cuda.synchronize()
+            if not self._text_ar_in_graph:
+                self._g_text_bwd = cap(eng._text_backward)
             # RPO_BWD_PARTS = P > 1: the image tower's prompt-row chain as P independent chains over B / P images each, on
             # P streams (Engine._image_backward_rows: the rows of different images never meet before the batch sum)
             P = int(_xenv("RPO_BWD_PARTS", "1"))
@@ -201,7 +225,7 @@ class RPO:
             # N > 1: the text tower's gradient is complete here, ~0.15-0.3 ms before the image tower's: its all-reduce
             # goes out now, behind the text chain on the side stream, and travels under the image backward
             # (RPO_ONE_COLLECTIVE=1: one all-reduce of the whole buffer after the join, as before)
-            if self._split_collective:
+            if self._split_collective and not self._text_ar_in_graph:
                 self.sync.all_reduce_sum(self.engine.g_text_flat)
             self._ev_text_bwd.record(side)
         if self._bwd_parts > 1:
@@ -248,22 +272,43 @@ class RPO:
             self._replay()
         else:
             eng.forward_backward(self._image, self._label)
+        if self.amp and self._found_inf is None:
+            self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device)
+        tail = None
+        if self.use_graph and getattr(self, "_graph_collectives", False) and self._steps > 0:
+            tail = self._tail_graphs.get(self.lr)               # the rate is a kernel argument: one small graph per rate
+            if tail is None:
+                try:
+                    tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(tail, capture_error_mode="thread_local"):
+                        self._tail()
+                    self._tail_graphs[self.lr] = tail
+                except Exception as ex:             # noqa: BLE001
+                    print(f"[rpo_amd] capturing the step's tail failed ({type(ex).__name__}: {ex}); it stays eager")
+                    self._graph_collectives, tail = False, None
+                    torch.cuda.synchronize()
+        if tail is not None:
+            tail.replay()
+        else:
+            self._tail()
+        self._steps += 1
+        eng.params_version += 1
+        eng.text_f_version = -1
+        return eng.loss
+
+    def _tail(self) -> None:
+        """What follows the two backward chains: the all-reduce of what is still local, then the fused SGD step."""
+        eng, oc = self.engine, self.optim_cfg
         if self.use_graph and self._split_collective and not self._joint_bwd:
             self.sync.all_reduce_sum(eng.g_img_flat)            # (g_text went out behind the text backward, _replay)
         else:
             self.sync.all_reduce_sum(eng.grads)
         if self.amp:
-            if self._found_inf is None:
-                self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device)
             ops.sgd_step_guarded(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
                                  self.sync.grad_scale, first_step=(self._steps == 0), found_inf=self._found_inf)
         else:
             ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
                          self.sync.grad_scale, first_step=(self._steps == 0))
-        self._steps += 1
-        eng.params_version += 1
-        eng.text_f_version = -1
-        return eng.loss
 
     def update_lr(self) -> None:
         self.epoch += 1

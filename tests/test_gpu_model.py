@@ -322,6 +322,14 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert np.isfinite(d["config"]["final_loss"]) and d["config"]["collective"].startswith("rccl")
+    # round 5: the two all-reduces and the SGD launch are captured in the step's HIP graphs (RCCL under stream capture);
+    # the same run with eager collectives (RPO_NO_GRAPH_COLLECTIVES=1) must end at the same loss
+    assert d["config"]["collectives_in_graph"] is True and d["config"]["host_us_per_step"] > 0
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, RPO_NO_GRAPH_COLLECTIVES="1"), cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["config"]["collectives_in_graph"] is False
+    assert d2["config"]["final_loss"] == d["config"]["final_loss"]
 
 
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
@@ -379,7 +387,9 @@ def test_bench_eight_rank_flow_on_one_gpu():
     assert "cpu_baseline" not in d and "precision" not in d      # N = 1 only
     # round 4: the text half of the gradient goes out behind the text chain, the image half after the image chain; the
     # line carries every rank's own step time and what the host pinning did
-    assert d["config"]["collective_schedule"].startswith("split") and 0 < d["config"]["collective_share_of_step"] < 1
+    # (the split schedule needs an asynchronous backend: under this test's gloo stand-in the trainer keeps ONE all-reduce
+    #  after the join -- round-4 advisor; test_bench_runs_under_torchrun_with_rccl covers the RCCL schedule)
+    assert d["config"]["collective_schedule"].startswith("one all-reduce") and 0 < d["config"]["collective_share_of_step"] < 1
     rk = d["config"]["rank_ms_per_step"]
     assert len(rk["all"]) == 8 and rk["min"] <= rk["max"] and abs(rk["max"] - d["ms_per_step"]) < 1e-3
     assert "pinned" in d["config"]["host"]
@@ -993,8 +1003,8 @@ def test_coop_checkpoints_amp_and_cocoop_test_batches(tmp_path):
     co2.load_model(str(tmp_path / "cocoop"), epoch=3)
     assert torch.equal(co2.engine.coop_params, co.engine.coop_params) and co2.epoch == 0
     assert co2.resume_model(str(tmp_path / "cocoop"), epoch=3) == 3 and co2.epoch == 3
-    with pytest.raises(ValueError):                              # momentum of another context shape: refused, not half-applied
-        CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3).resume_model(str(tmp_path))
+    with pytest.raises((ValueError, RuntimeError)):              # a checkpoint of another context shape (CSC) is refused,
+        CoOp(sd, toks, 4, oc, "cuda:0", torch.float32, batch_size=3).resume_model(str(tmp_path))   # not half-applied
 
 
 def test_coop_trainer_sgd_steps_match_oracle():
