@@ -231,10 +231,6 @@ class Engine:
         self.text_proj_t, self.text_proj = self._act(tp.t()), self._act(tp)
         for w in (self.img_proj_t, self.img_proj, self.text_proj_t, self.text_proj):
             self._ws_reg(w)
-        # K = 48 on ViT-B/16 (245 rows per image): c_fc of every block runs its prompt rows as their own launch (_image_forward)
-        if cfg.n_frozen <= 224 < cfg.n_frozen + cfg.K <= 256:
-            for blk in self.vis:
-                self._ws_reg(blk.w_fc_ln)
         # small batches (config 1: batch 4): the WHOLE image forward is a small-M problem -- B x (N + K) < 2048 rows, no
         # one-round geometry -- so every block's forward weights get a packed twin too (RPO_WS_SMALL=0: not).  B x (N + K) < 1024.
         self.ws_small = (self.use_ws and self.max_batch * (cfg.n_frozen + cfg.K) < 1024 and os.environ.get("RPO_WS_SMALL", "1") != "0")
@@ -501,10 +497,6 @@ class Engine:
                 b = self.vis[l]
             return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
                     "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
-        # c_fc in two launches (see the block loop): whole-batch blocks, 16-bit modes with the LayerNorm fold, a batch whose
-        # frozen rows tile one round (B x 8 column tiles = a multiple of the CUs) and units of 225 .. 256 rows
-        cfc_split = (fold and self.use_ws and not split and not small and not full_last and N <= 224 < N + K <= 256
-                     and dv == 768 and (B * 8) % 256 == 0 and os.environ.get("RPO_NO_CFC_SPLIT") != "1")
         no_probe = lambda name: _NO_PROBE
         mlp_fused = _xenv("RPO_MLP_FUSED", "0")
         mlp_fused = mlp_fused if mlp_fused in ("1", "safe") and self.act != torch.float32 else ""
@@ -589,18 +581,7 @@ class Engine:
                         done = ops.mlp_fused(fc_kw, proj_kw, self.mlp_counters, safe=(mlp_fused == "safe"))
                     if done:
                         continue
-                if fold and wide and cfc_split:
-                    # c_fc where an image's N + K rows do not fit the one-round 224x384 tiles but its N frozen rows do
-                    # (ViT-B/16 at K = 48): the frozen rows as ONE round of row-unit tiles (N + 0 rows per unit), the
-                    # B*K prompt rows -- the only ones with a saved QuickGELU operand -- on rpo_gemm_ws.  Both read the
-                    # statistics out-proj left for all rows.
-                    with timed("c_fc"):
-                        ops.gemm_nt(h[:Rf], blk.w_fc_ln, g[:Rf], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln, aux=None, aux_row0=Rf,
-                                    ln_stats=so[:Rf], ln_colsum=blk.s_fc, row_units=(N, 0, Rf), ln_group=go,
-                                    prefetch=pf_of("fc", l))
-                        self._gemm(h[Rf:hi], blk.w_fc_ln, g[Rf:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln, aux=aux, aux_row0=0,
-                                   ln_stats=so[Rf:hi], ln_colsum=blk.s_fc, ln_group=go)
-                elif fold:
+                if fold:
                     with timed("c_fc"):
                         gemm(h[lo:hi], blk.w_fc_ln, g[lo:hi], EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                              aux=aux, aux_row0=aux_row0,
