@@ -95,6 +95,11 @@ class Engine:
         self.use_ws = act_dtype != torch.float32 and os.environ.get("RPO_NO_WS") != "1"
         self._wsp: Dict[tuple, "ops.PackedWeight"] = {}   # (data_ptr, shape) of a row-major weight -> its packed twin
         self._ws_okc: Dict[tuple, bool] = {}
+        self._ws_cfg = 0
+        # The text tower is not on the step's critical path; what it costs is its kernels' footprint beside the image stream.
+        # Its GEMMs therefore run on 64x64 tiles (a quarter of the workgroups of the 32x32 tiles the kernel would pick for
+        # itself: each launch is slower alone, the step 0.8 % faster -- profiles/r05_ab_ws_text_tiles.txt).  0 = the kernel's choice.
+        self._ws_text_cfg = int(os.environ.get("RPO_WS_TEXT_CFG", "220"))
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -200,6 +205,8 @@ class Engine:
             if ok is None:
                 ok = self._ws_okc[key] = (M < 2048 and ops.gemm_ws_ok(M, pw.N, pw.K, self.act, out.dtype, epilogue, split, key[-1]))
             if ok:
+                if self._ws_cfg and "tile_config" not in kw:          # (the text tower's geometry: see __init__)
+                    kw["tile_config"] = self._ws_cfg
                 pf = kw.get("prefetch")
                 if pf is not None:
                     kw["prefetch"] = self._wsp.get((pf.data_ptr(), tuple(pf.shape)), pf)
@@ -373,6 +380,13 @@ class Engine:
 
     # ------------------------------------------------------------------ forward pieces
     def _text_forward(self, train: bool) -> None:
+        self._ws_cfg = self._ws_text_cfg
+        try:
+            self._text_forward_(train)
+        finally:
+            self._ws_cfg = 0
+
+    def _text_forward_(self, train: bool) -> None:
         cfg = self.cfg
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         ops.broadcast_rows(self.text_prompt, self.xt[0], n)          # trainers/rpo.py:176-177
@@ -823,6 +837,13 @@ class Engine:
         ops.reduce_groups(T["dxa"], self.g_text, n)
 
     def _text_backward(self) -> None:
+        self._ws_cfg = self._ws_text_cfg
+        try:
+            self._text_backward_()
+        finally:
+            self._ws_cfg = 0
+
+    def _text_backward_(self) -> None:
         cfg = self.cfg
         n, K, dt, H, Rt = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t, self.Rt
         dxa, dxb, dxc = self.dxa_t, self.dxb_t, self.dxc_t
