@@ -642,10 +642,14 @@ class Engine:
         pf = self._pf_chains
         # split-K factors of the two fp32-output dX GEMMs (slabs summed in fixed order by rpo_layernorm_bwd).  On
         # rpo_gemm_ws the waves of a workgroup already split k four ways: d q-proj runs unsplit (one slab less for the
-        # LayerNorm backward to read) and d c_fc in 4 (K = 4d >= 3072: 96x96 tiles x 4 = one round of the CUs at
-        # 768 rows) or 2 (the text tower's K = 2048) -- tools/bench_gemm_ws.py, profiles/r05_bench_gemm_ws.txt
+        # LayerNorm backward to read) and d c_fc in TWO.  Alone, four slabs are the faster launch at 768 rows (96x96 tiles
+        # x 4 = one round of the CUs: 9.0 vs 10.7 us, profiles/r05_bench_gemm_ws.txt), but in the step two slabs win
+        # (-0.85 % step time, three alternating pairs, profiles/r05_ab_ws_splits.txt): half the workgroups beside the text
+        # tower and half the slab bytes for the LayerNorm backward behind it.
         d = blocks[0].w_q_t.shape[0] if blocks else 0
-        s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not self.use_ws else ((4 if dxa.shape[0] >= 256 else 3) if d >= 768 else 2, 1)
+        s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not self.use_ws else (2, 1)
+        if self.use_ws and "RPO_WS_SPLITS" in os.environ:             # A/B: "FCxQ" (step-level tuning, tools/ab_env.py)
+            s_fc, s_q = (int(v) for v in os.environ["RPO_WS_SPLITS"].split("x"))
         for l in reversed(range(len(blocks))):
             blk = blocks[l]
             a_in = dxa if self.act == torch.float32 else dxc
