@@ -370,7 +370,7 @@ def committed_qkv_gemm(args):
         elif sect and line.startswith("-> MFMA busy / wave lifetime"):
             res["mfma_busy_lifetime"] = float(line.split()[-1])
         elif sect and line.startswith("-> MFMA busy / (duration x clk)"):
-            res["mfma_busy"] = float(line.split()[6])
+            res["mfma_busy"] = float(line.split("clk)")[1].split()[0])
     # the figure held against 0.70: busy shader cycles over (launch duration x the shader clock measured in the kernel) --
     # one clock domain; `_wall` (GRBM window, another clock) and `_lifetime` (waves only: no ramp / write-back) bracket it
     res["met"] = res.get("mfma_busy", res.get("mfma_busy_wall", 0.0)) >= 0.70
