@@ -99,7 +99,11 @@ class Engine:
         # The text tower is not on the step's critical path; what it costs is its kernels' footprint beside the image stream.
         # Its GEMMs therefore run on 64x64 tiles (a quarter of the workgroups of the 32x32 tiles the kernel would pick for
         # itself: each launch is slower alone, the step 0.8 % faster -- profiles/r05_ab_ws_text_tiles.txt).  0 = the kernel's choice.
-        self._ws_text_cfg = int(os.environ.get("RPO_WS_TEXT_CFG", "220"))
+        # Only where the image forward is long enough to hide the slower text launches (>= 6000 token rows: batch 32 of
+        # ViT-B/16): at batch 4 / 8 / 16 the text chain is on the critical path and the kernel's own choice wins by 3.2 / 2.9
+        # / 0.6 % (same file).
+        big = max_batch * (cfg.n_frozen + cfg.K) >= 6000
+        self._ws_text_cfg = int(os.environ.get("RPO_WS_TEXT_CFG", "220" if big else "0"))
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
