@@ -36,6 +36,26 @@ def test_library_exports_every_declared_symbol():
     assert b"shape" in _lib.load().rpo_error_string(-2)
 
 
+def test_experiments_live_only_in_the_experimental_library():
+    """include/rpo_amd_experimental.h: every entry point it declares is exported by the -DRPO_EXPERIMENTAL build and by
+    that build alone -- the product library and the product header carry none of it."""
+    from rpo_amd import _lib
+    from rpo_amd.build import LIB_EXP, build_library
+    build_library()
+    build_library(experimental=True)
+    src = open(os.path.join(ROOT, "include", "rpo_amd_experimental.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    exp = sorted(set(re.findall(r"\b(rpo_[a-z0-9_]+)\s*\(", src)))
+    assert exp and sorted(_lib.EXPERIMENTAL_SIGNATURES) == exp
+    assert not set(exp) & set(_header_functions())
+    product, experimental = ctypes.CDLL(_lib.LIB_PATH), ctypes.CDLL(LIB_EXP)
+    for n in exp:
+        assert not hasattr(product, n), f"librpo_hip.so exports the experiment {n}"
+        assert hasattr(experimental, n), f"librpo_hip_exp.so does not export {n}"
+    for n in _header_functions():
+        assert hasattr(experimental, n)
+
+
 def test_gemm_args_struct_matches_header_field_order():
     from rpo_amd._lib import GemmArgs
     src = open(os.path.join(ROOT, "include", "rpo_amd.h")).read()

@@ -1,6 +1,8 @@
 """Pin the oracle: the dense CPU restatement must reproduce what the REAL
 reference (trainers/rpo.py CustomCLIP, imported by tools/make_golden.py in the
 build container) produced on the same generated weights / inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,7 +11,7 @@ from oracle import rpo_oracle
 from rpo_amd import synth
 from rpo_amd.config import flops_image, flops_text, vit_b16, vit_l14
 
-from helpers import CASES, load_golden, oracle_for, workload
+from helpers import CASES, GOLDEN, load_golden, oracle_for, workload
 
 FAST = ["d1_k4_b2", "d2_k8_b3", "d2_k24_b2_init", "d2_k16_b2", "d2_k48_b2"]
 
@@ -130,6 +132,34 @@ def test_sgd_steps_match_reference(tag):
             np.testing.assert_allclose(m.text_prompt.detach().numpy(), g[f"text_prompt_step{step + 1}"], atol=2e-6)
             np.testing.assert_allclose(m.img_prompt.detach().numpy(), g[f"img_prompt_step{step + 1}"], atol=2e-6)
     np.testing.assert_allclose(losses, g["sgd_losses"], atol=3e-5)
+
+
+def test_oracle_follows_reference_trajectory_through_the_warmup_boundary():
+    """The 60-step run of the REAL reference (tools/make_golden_trajectory.py: BASELINE.json configs[0]): both
+    restatements of the schedule give the reference's learning rate for all 15 epochs, and the oracle -- stepped with
+    them -- reproduces the first two epochs (constant warm-up, then the first epoch at the full rate): the prompts
+    after epoch 1 and the 8 losses, the last four of which already depend on updates made at lr 0.01."""
+    from rpo_amd.trainer import OptimConfig, lr_at_epoch
+    g = dict(np.load(os.path.join(GOLDEN, "ref_traj_d12_k24_b4_e15.npz")))
+    lr, mom, wd, max_epoch, iters, B, warm, cons = g["hparams"]
+    max_epoch, iters, B, warm = int(max_epoch), int(iters), int(B), int(warm)
+    oc = OptimConfig(lr=lr, max_epoch=max_epoch, warmup_epoch=warm, warmup_cons_lr=cons, momentum=mom, weight_decay=wd)
+    for e in range(max_epoch):
+        assert abs(lr_at_epoch(oc, e) - g["lrs"][e]) < 1e-15
+        assert abs(rpo_oracle.cosine_lr_with_constant_warmup(lr, e, max_epoch, warm, cons) - g["lrs"][e]) < 1e-15
+    cfg, sd, toks, tp, ip, _, _ = workload("d12_k24_b4")
+    assert g["weights_crc"].item().decode() == synth.state_dict_checksum(sd)
+    m, _, _ = oracle_for("d12_k24_b4")
+    opt = rpo_oracle.OracleSGD(lr, mom, wd)
+    batches = [(synth.images(cfg, B, seed=1234 + 10 * i), synth.labels(cfg, B, seed=4321 + 10 * i)) for i in range(iters)]
+    losses = []
+    for e in range(2):
+        opt.lr = rpo_oracle.cosine_lr_with_constant_warmup(lr, e, max_epoch, warm, cons)
+        losses += rpo_oracle.train_steps(m, opt, batches)
+        if e == 0:
+            np.testing.assert_allclose(m.text_prompt.detach().numpy(), g["text_prompt_e1"], atol=2e-6)
+            np.testing.assert_allclose(m.img_prompt.detach().numpy(), g["img_prompt_e1"], atol=2e-6)
+    np.testing.assert_allclose(losses, g["losses"][:2 * iters], atol=5e-5)
 
 
 def test_algorithmic_flops_match_survey():
