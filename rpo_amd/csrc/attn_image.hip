@@ -1139,7 +1139,144 @@ int dispatch_bwd_proj(int ncw, bool big, const void* qr, int64_t ldq, const void
 }
 
 
+// ---- text tower, prompt rows (round 5): one WAVE per (class, head) -------------------------------------------------------
+// The prompt rows of a class read only that class's frozen tokens (trainers/rpo.py:144-151): K <= 64 queries against
+// len_c keys -- 8 .. 14 for the Oxford-Pets prompts, <= 77 for any CLIP prompt -- per (class, head).  That is one or two
+// 32x32 MFMA tiles, so a single wave holds the whole problem in registers: K and V rows come straight from the row-major
+// K / V cache as A-operand fragments (16 B per lane), S^T = K . Q^T leaves a lane with ONE query's scores (softmax =
+// in-register reduce + one cross-half exchange), V^T / K^T for the second contraction are formed on the matrix core
+// (transpose_tile: exact), P / dS go from the C/D registers straight into the B operand.  No LDS, no barrier, 64 threads.
+// It replaces the VALU kernel of attn_text.hip (912 workgroups of 256 threads for the same work) in the 16-bit modes.
+//   forward : out = softmax(scale q K^T) V                                      (clip/model.py:186 under the mask above)
+//   backward: dq = scale * sum_key dS[key] K[key],  dS = P (dP - sum P dP),  dP = da V^T   (K, V frozen: no dK, dV)
+template <typename T, bool BWD, int NKT>
+__global__ __launch_bounds__(64) void text_attn_wave_kernel(const T* q, int64_t ldq, const T* kc, const T* vc, int64_t ldkv,
+                                                            const T* da, int64_t ldda, T* out, int64_t ldo,
+                                                            const int32_t* __restrict__ len, int rows, int Lmax, int H,
+                                                            float scale) {
+  const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+  const int c = blockIdx.x / H, h = blockIdx.x % H;
+  const int L = min(len[c], Lmax);
+  RowFrag<T> kf[NKT], vf[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {          // keys >= L: the last key again (scores masked, p = 0 exactly)
+    const int64_t base = ((int64_t)c * Lmax + max(min(32 * t + l31, L - 1), 0)) * ldkv + h * 64;
+    kf[t].load(kc + base, half);
+    vf[t].load(vc + base, half);
+  }
+  const bf16x8_t i0 = ident_frag<T>(0, l31, half), i1 = ident_frag<T>(1, l31, half);
+  for (int r0 = 0; r0 < rows; r0 += 32) {
+    const int r = r0 + l31;
+    const int64_t row = (int64_t)c * rows + min(r, rows - 1);
+    RowFrag<T> qf, df;
+    qf.load(q + row * ldq + h * 64, half);
+    if constexpr (BWD) df.load(da + row * ldda + h * 64, half);
+    f32x16_t s[NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[t] = mfma16<T>(kf[t].f[ks], qf.f[ks], s[t]);
+      m = fmaxf(m, mask_and_max(s[t], t, L, half));
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) l += exp_tile<T>(s[t], m, scale);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float fin = inv;
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        float w[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e] = s[t][e];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t vt[2];
+          transpose_tile<T>(vf[t].f, dt, i0, i1, vt);
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) o[dt] = mfma16<T>(vt[g2], pack8<T>(w + 8 * g2), o[dt]);
+        }
+      }
+    } else {
+      f32x16_t dp[NKT];
+      float delta = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[t][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp[t] = mfma16<T>(vf[t].f[ks], df.f[ks], dp[t]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[t][e] *= inv; delta = fmaf(s[t][e], dp[t][e], delta); }
+      }
+      delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        float w[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e] = s[t][e] * (dp[t][e] - delta);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t kt[2];
+          transpose_tile<T>(kf[t].f, dt, i0, i1, kt);
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) o[dt] = mfma16<T>(kt[g2], pack8<T>(w + 8 * g2), o[dt]);
+        }
+      }
+      fin = scale;
+    }
+    if (r < rows) {
+      T* orow = out + row * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g] * fin, o[dt][4 * g + 1] * fin,
+                        o[dt][4 * g + 2] * fin, o[dt][4 * g + 3] * fin);
+    }
+  }
+}
+
+template <typename T, bool BWD>
+int launch_text_wave(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da, int64_t ldda,
+                     void* out, int64_t ldo, const int32_t* len, int n_cls, int rows, int Lmax, int H, float scale,
+                     hipStream_t s) {
+#define RPO_TW(NKT)                                                                                                   \
+  hipLaunchKernelGGL((text_attn_wave_kernel<T, BWD, NKT>), dim3(n_cls * H), dim3(64), 0, s, static_cast<const T*>(q), \
+                     ldq, static_cast<const T*>(kc), static_cast<const T*>(vc), ldkv, static_cast<const T*>(da), ldda, \
+                     static_cast<T*>(out), ldo, len, rows, Lmax, H, scale)
+  if (Lmax <= 32) RPO_TW(1);
+  else if (Lmax <= 64) RPO_TW(2);
+  else RPO_TW(3);
+#undef RPO_TW
+  return rpo_launch_status();
+}
+
 }  // namespace
+
+// 16-bit storage, rows <= 64 prompt queries per class, Lmax <= 96 keys, 16-byte aligned rows: the one-wave kernel above;
+// RPO_E_SHAPE otherwise (the caller, attn_text.hip, then runs its VALU kernel).  bwd: `da` = d(attention output), `out` = dq.
+int rpo_text_attn_wave(int bwd, const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
+                       int64_t ldda, void* out, int64_t ldo, int dtype, const int32_t* len, int n_cls, int rows, int Lmax,
+                       int H, float scale, hipStream_t s) {
+  if ((dtype != RPO_BF16 && dtype != RPO_F16) || rows > 64 || Lmax > 96) return RPO_E_SHAPE;
+  if (!aligned16(q) || (ldq * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) || (ldo * 2) % 8 != 0) return RPO_E_SHAPE;
+  if (bwd && (!aligned16(da) || (ldda * 2) % 16 != 0)) return RPO_E_SHAPE;
+  if (dtype == RPO_BF16)
+    return bwd ? launch_text_wave<bf16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, out, ldo, len, n_cls, rows, Lmax, H, scale, s)
+               : launch_text_wave<bf16_t, false>(q, ldq, kc, vc, ldkv, da, ldda, out, ldo, len, n_cls, rows, Lmax, H, scale, s);
+  return bwd ? launch_text_wave<f16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, out, ldo, len, n_cls, rows, Lmax, H, scale, s)
+             : launch_text_wave<f16_t, false>(q, ldq, kc, vc, ldkv, da, ldda, out, ldo, len, n_cls, rows, Lmax, H, scale, s);
+}
 
 #ifndef RPO_DEVICE_ONLY     // (chain.hip includes this file for the device bodies above)
 extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld, void* out,

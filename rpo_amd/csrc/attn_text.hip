@@ -217,6 +217,9 @@ int launch_dense(const void* q, const void* k, const void* v, int64_t ld, const 
   return rpo_launch_status();
 }
 
+#ifndef RPO_TEXT_ROWS_PER_WG
+#define RPO_TEXT_ROWS_PER_WG 4          // query rows per workgroup (one per wave and pass); A/B: tools/build_variant.sh
+#endif
 template <typename T, bool BWD>
 int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
            int64_t ldda, void* out, int64_t ldo, const int32_t* len, int n_cls, int rows, int Lmax, int H,
@@ -225,7 +228,7 @@ int launch(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t l
   auto kern = text_attn_kernel<T, BWD>;
   const int bytes = 2 * Lmax * 65 * 4;
   if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(kern), 2 * 128 * 65 * 4, &lds_ok)) return rc;
-  hipLaunchKernelGGL(kern, dim3(n_cls * H, (rows + 3) / 4), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
+  hipLaunchKernelGGL(kern, dim3(n_cls * H, (rows + RPO_TEXT_ROWS_PER_WG - 1) / RPO_TEXT_ROWS_PER_WG), dim3(256), bytes, s, static_cast<const T*>(q), ldq,
                      static_cast<const T*>(kc), static_cast<const T*>(vc), ldkv, static_cast<const T*>(da), ldda,
                      static_cast<T*>(out), ldo, len, rows, Lmax, H, causal, scale);
   return rpo_launch_status();
@@ -243,6 +246,12 @@ extern "C" int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, con
     if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+#ifndef RPO_TEXT_ATTN_VALU
+  if (!causal) {
+    const int rc = rpo_text_attn_wave(0, q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, dtype, len, n_cls, rows, Lmax, H, scale, s);
+    if (rc != RPO_E_SHAPE) return rc;
+  }
+#endif
   if (dtype == RPO_F16)
     return launch<f16_t, false>(q, ldq, kc, vc, ldkv, nullptr, 0, out, ldo, len, n_cls, rows, Lmax, H, causal, scale, s);
   if (dtype == RPO_BF16)
@@ -263,6 +272,12 @@ extern "C" int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, con
     if (!aligned16(kc) || !aligned16(vc) || (ldkv * esz) % 16 != 0) return RPO_E_ALIGN;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+#ifndef RPO_TEXT_ATTN_VALU
+  {
+    const int rc = rpo_text_attn_wave(1, q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, dtype, len, n_cls, rows, Lmax, H, scale, s);
+    if (rc != RPO_E_SHAPE) return rc;
+  }
+#endif
   if (dtype == RPO_F16)
     return launch<f16_t, true>(q, ldq, kc, vc, ldkv, da, ldda, dq, lddq, len, n_cls, rows, Lmax, H, 0, scale, s);
   if (dtype == RPO_BF16)

@@ -220,6 +220,12 @@ static inline int rpo_cu_count() {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// attn_image.hip: the prompt-row attention of the text tower as one wave per (class, head) (16-bit modes); RPO_E_SHAPE
+// where it does not apply.  Called by rpo_text_attn_fwd / rpo_text_attn_bwd (attn_text.hip) ahead of their VALU kernel.
+int rpo_text_attn_wave(int bwd, const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
+                       int64_t ldda, void* out, int64_t ldo, int dtype, const int32_t* len, int n_cls, int rows, int Lmax,
+                       int H, float scale, hipStream_t s);
+
 // Optional in-kernel timeline (debug build with -DRPO_TIMELINE; tools/gemm_timeline.py, tools/attn_timeline.py):
 // thread 0 of a few workgroups stamps s_memtime at phase boundaries into a global buffer.
 #ifdef RPO_TIMELINE

@@ -913,11 +913,13 @@ def _paired_attention_case(o, dt, D, B):
     assert torch.equal(dqi, dqi3), "rpo_attn_bwd_proj_pair differs from rpo_attn_readonly_bwd_proj"
 
 
+# (16-bit modes, <= 64 query rows, <= 96 keys: the one-wave MFMA kernel with 3 / 1 / 2 key tiles and 1 / 1 / 2 query tiles;
+#  f32 and the causal pass: the VALU kernel)
+@pytest.mark.parametrize("lens,Kr", [([3, 71, 20, 8, 10], 6), ([10, 10, 14, 11, 8, 1], 24), ([33, 40, 5], 48)])
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
-def test_text_attn_fwd_bwd(mode):
+def test_text_attn_fwd_bwd(mode, lens, Kr):
     o = ops()
-    lens = [3, 71, 20, 8, 10]
-    n, H, Kr, Lmax = len(lens), 2, 6, 71
+    n, H, Lmax = len(lens), 2, max(lens)
     d = 64 * H
     kv = rnd((n * Lmax, 2 * d), 21)
     qr, da = rnd((n * Kr, d), 22, 1.5), rnd((n * Kr, d), 23)

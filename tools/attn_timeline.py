@@ -18,7 +18,10 @@ dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
 H, N, Kp, d = 12, 197, 24, 768
-names = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "S^T done", "softmax done", "PV+store issued", "stores drained"]
+# stamps 4 / 5 exist only in the -DRPO_ATTN_FWD_V2 variant (scores of a whole query tile in registers); the shipped
+# online-softmax kernel goes from "barrier passed" straight to "key loop + stores issued": absent stamps are skipped
+names = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "S^T done", "softmax done",
+         "key loop (S^T, softmax, P.V) + stores issued", "stores drained"]
 for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
     qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
     out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
@@ -36,4 +39,6 @@ for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
     for b in range(4):
         r = t[b]
         if r[0] == 0: continue
-        print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[i-1])}" for i in range(1, 8)) + f" | total {int(r[7]-r[0])}")
+        have = [i for i in range(8) if r[i] != 0]
+        assert have[0] == 0 and have[-1] == 7 and all(r[a] <= r[b] for a, b in zip(have, have[1:])), r
+        print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[j])}" for j, i in zip(have, have[1:])) + f" | total {int(r[7]-r[0])}")
