@@ -1263,6 +1263,7 @@ int launch_text_wave(const void* q, int64_t ldq, const void* kc, const void* vc,
 
 }  // namespace
 
+#ifndef RPO_DEVICE_ONLY     // (chain.hip includes this file for the device bodies above)
 // 16-bit storage, rows <= 64 prompt queries per class, Lmax <= 96 keys, 16-byte aligned rows: the one-wave kernel above;
 // RPO_E_SHAPE otherwise (the caller, attn_text.hip, then runs its VALU kernel).  bwd: `da` = d(attention output), `out` = dq.
 int rpo_text_attn_wave(int bwd, const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv, const void* da,
@@ -1278,7 +1279,6 @@ int rpo_text_attn_wave(int bwd, const void* q, int64_t ldq, const void* kc, cons
              : launch_text_wave<f16_t, false>(q, ldq, kc, vc, ldkv, da, ldda, out, ldo, len, n_cls, rows, Lmax, H, scale, s);
 }
 
-#ifndef RPO_DEVICE_ONLY     // (chain.hip includes this file for the device bodies above)
 extern "C" int rpo_attn_readonly_fwd_rows(const void* q, const void* k, const void* v, int64_t ld, void* out,
                                           int64_t ldo, int dtype, int B, int H, int N, int Kp, float scale,
                                           int q_first, void* stream);
