@@ -50,6 +50,7 @@ timeout 200 python bench.py --steps 20 --warmup 5 --eval-batch 100 $B > $O/bench
 timeout 300 python bench.py --trainer coop --steps 30 --warmup 5 --no-precision > $O/bench_coop.json 2>> $O/bench.err
 timeout 300 python bench.py --trainer cocoop --steps 30 --warmup 5 --no-precision > $O/bench_cocoop.json 2>> $O/bench.err
 keep attn_timeline.txt 200 python tools/attn_timeline.py 8 16 32
+keep attn_bwd_timeline.txt 200 python tools/attn_bwd_timeline.py
 keep gemm_timeline.txt 200 python tools/gemm_timeline.py
 keep gemm_ws_timeline.txt 200 python tools/gemm_ws_timeline.py
 keep graph_phases.txt 100 python tools/probe_graph_launch.py
@@ -57,6 +58,7 @@ keep graph_phases.txt 100 python tools/probe_graph_launch.py
 keep per_layer_probe.txt 100 python tools/probe_per_layer.py
 [ -z "${QUICK:-}" ] && BENCH_CFGS=2,3,7,8,10 keep bench_gemm.txt 200 python tools/bench_gemm.py
 keep bench_gemm_ws.txt 300 python tools/bench_gemm_ws.py
+keep bench_text_attn.txt 100 python tools/bench_text_attn.py
 [ -z "${QUICK:-}" ] && [ -x tools/build/ubench_dma ] && keep ubench_dma.txt 100 tools/build/ubench_dma
 # the image tower as P part-batches on P streams (round 3: does de-phasing the one-round kernels help?)
 [ -z "${QUICK:-}" ] && keep half_batch_probe.txt 200 python tools/probe_half_batch.py 32 1 2 4

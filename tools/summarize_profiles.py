@@ -176,7 +176,7 @@ for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_f1
         shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
 bad = False
 for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt", "cu_mask_probe.txt",
-           "attn_timeline.txt", "half_batch_probe.txt", "gemm_ws_timeline.txt", "bench_gemm_ws.txt"):
+           "attn_timeline.txt", "attn_bwd_timeline.txt", "half_batch_probe.txt", "gemm_ws_timeline.txt", "bench_gemm_ws.txt", "bench_text_attn.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
