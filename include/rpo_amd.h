@@ -263,11 +263,16 @@ int rpo_attn_readonly_bwd_proj(const void* q_rows, int64_t ldq, const void* k, c
  * causal = 0: every row reads keys [0, len[c])            (prompt rows, trainers/rpo.py:146-149:
  *             causal AND col < len_c, and prompts sit at positions >= len_c)
  * causal = 1: row t reads keys [0, min(t + 1, len[c]))     (the one-off pass over the frozen tokens)
- * len: int32 device array [n_cls].  Lmax <= 128. */
+ * len: int32 device array [n_cls].  Lmax <= 128.
+ * Kernels: 16-bit storage, causal = 0, rows <= 64, Lmax <= 96, 16-byte aligned rows -- the training path's shapes -- run as
+ * ONE WAVE per (class, head) on the matrix cores (fp32 accumulation and softmax; P and dS rounded to the storage type for
+ * the second contraction, as in rpo_attn_readonly_fwd); everything else as fp32 VALU arithmetic.  Same meaning either way. */
 int rpo_text_attn_fwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
                       void* out, int64_t ldo, int dtype, const int32_t* len, int n_cls, int rows,
                       int Lmax, int H, int causal, float scale, void* stream);
 
+/* dq = d(loss)/d(q) of the causal = 0 case given da = d(loss)/d(out); K and V are frozen (no dk, dv).  Replaces the autograd of
+ * nn.MultiheadAttention's SDPA (clip/model.py:186, trainers/rpo.py:308) for the text tower's prompt rows. */
 int rpo_text_attn_bwd(const void* q, int64_t ldq, const void* kc, const void* vc, int64_t ldkv,
                       const void* da, int64_t ldda, void* dq, int64_t lddq, int dtype,
                       const int32_t* len, int n_cls, int rows, int Lmax, int H, float scale, void* stream);

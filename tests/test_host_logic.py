@@ -459,6 +459,11 @@ def test_committed_profiles_are_measurements_not_crash_logs():
         if "Traceback (most recent call last)" in txt or re.search(r"(^|\s)(warning|error):", txt):
             bad.append(os.path.basename(f))
     assert not bad, f"profiles that are not measurements: {bad}"
+    # in-kernel timelines of this round onwards: every phase delta is a plausible cycle count (a stamp the kernel does
+    # not have once showed up as "+-393995800630558")
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r0[5-9]_*timeline.txt"))):
+        for m in re.finditer(r"\+(-?\d+)", open(f).read()):
+            assert 0 <= int(m.group(1)) < 10 ** 7, f"{os.path.basename(f)}: phase delta {m.group(1)}"
     sh = open(os.path.join(root, "tools", "collect_profiles.sh")).read()
     assert "keep()" in sh and "exit 1" in sh and "Traceback (most recent call last)" in sh
     assert "REFUSED" in open(os.path.join(root, "tools", "summarize_profiles.py")).read()
