@@ -21,5 +21,7 @@ for run in range(2):
     torch.cuda.synchronize()
     outs.append((tr.engine.params.clone(), tr.engine.loss.clone()))
     del tr
-print("bitwise equal params:", torch.equal(outs[0][0], outs[1][0]), "loss:", outs[0][1].item(), outs[1][1].item(),
-      "finite:", torch.isfinite(outs[0][0]).all().item())
+same, finite = torch.equal(outs[0][0], outs[1][0]), torch.isfinite(outs[0][0]).all().item()
+print("two runs of 300 graph-replayed steps (B = 32, bf16): bitwise equal params:", same, "loss:", outs[0][1].item(),
+      outs[1][1].item(), "finite:", finite)
+sys.exit(0 if same and finite else 1)
