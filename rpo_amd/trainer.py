@@ -282,6 +282,8 @@ class RPO:
                     tail = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(tail, capture_error_mode="thread_local"):
                         self._tail()
+                    if len(self._tail_graphs) >= 64:   # a schedule that changes the rate every step: keep the cache bounded
+                        self._tail_graphs.clear()
                     self._tail_graphs[self.lr] = tail
                 except Exception as ex:             # noqa: BLE001
                     print(f"[rpo_amd] capturing the step's tail failed ({type(ex).__name__}: {ex}); it stays eager")
