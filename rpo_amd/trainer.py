@@ -202,16 +202,32 @@ class RPO:
         self._ev_text_fwd = torch.cuda.Event()
         self._ev_head = torch.cuda.Event()
         self._ev_text_bwd = torch.cuda.Event()
+        # EARLY TEXT (round 5): the text tower's gradient is complete ~0.25 ms before the image tower's, and the next step's
+        # text forward needs nothing but the updated text prompts -- so the text half of the SGD step runs on the side
+        # stream right behind the text backward (and its all-reduce), and the NEXT step's text forward follows it there,
+        # under the tail of this step's image backward instead of beside the next image forward.  Every step still runs
+        # one text forward; `_text_fwd_for` says which prompt version the features on the device belong to, so anything
+        # that changes the prompts from outside (load_model, set_prompts) simply makes the next step compute them again.
+        # Not with amp (one found-inf verdict covers both halves), the paired-launch experiments or a whole-buffer
+        # collective.  Measured same-box (profiles/r05_ab_early_text.txt): batch 4 -1.0 %, batch 8 -0.4 %, batch 32 +0.7 % --
+        # at 32 images the text forward costs the image BACKWARD (the step's critical chain of small launches) more than it
+        # cost the image forward -- so it is on below 2048 image token rows per step only.  RPO_EARLY_TEXT=1 / =0 force it.
+        want = os.environ.get("RPO_EARLY_TEXT")
+        small = self.batch_size * (self.cfg.n_frozen + self.cfg.K) < 2048
+        self._early_text = ((want == "1" or (want is None and small)) and not self.amp and not self._joint_bwd
+                            and self._bwd_parts == 1 and (not self.sync.enabled or self._split_collective))
+        self._text_fwd_for = -1
         self._graph = True
         torch.cuda.synchronize()
 
     def _replay(self) -> None:
         main, side = torch.cuda.current_stream(), self.engine.side
         self._ev_fork.record(main)                  # inputs / updated prompts are ready
-        side.wait_event(self._ev_fork)
-        with torch.cuda.stream(side):
-            self._g_text_fwd.replay()
-            self._ev_text_fwd.record(side)
+        if not (self._early_text and self._text_fwd_for == self.engine.params_version):
+            side.wait_event(self._ev_fork)          # (early text: the previous step already ran this forward, see below)
+            with torch.cuda.stream(side):
+                self._g_text_fwd.replay()
+                self._ev_text_fwd.record(side)
         self._g_img_fwd.replay()
         main.wait_event(self._ev_text_fwd)
         self._g_head.replay()
@@ -227,7 +243,14 @@ class RPO:
             # (RPO_ONE_COLLECTIVE=1: one all-reduce of the whole buffer after the join, as before)
             if self._split_collective and not self._text_ar_in_graph:
                 self.sync.all_reduce_sum(self.engine.g_text_flat)
-            self._ev_text_bwd.record(side)
+            if self._early_text:
+                self._run_tail("text")              # SGD on the text prompts, then the NEXT step's text forward
+                self._ev_text_bwd.record(side)
+                self._g_text_fwd.replay()
+                self._ev_text_fwd.record(side)
+                self._text_fwd_for = self.engine.params_version + 1     # (step_async bumps the version after the tail)
+            else:
+                self._ev_text_bwd.record(side)
         if self._bwd_parts > 1:
             for st, ev, g in zip(self._part_streams, self._ev_parts, self._g_img_bwd_parts[1:]):
                 st.wait_event(self._ev_head)
@@ -274,17 +297,27 @@ class RPO:
             eng.forward_backward(self._image, self._label)
         if self.amp and self._found_inf is None:
             self._found_inf = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._run_tail("img" if (self.use_graph and getattr(self, "_early_text", False)) else "all")
+        self._steps += 1
+        eng.params_version += 1
+        eng.text_f_version = -1
+        return eng.loss
+
+    def _run_tail(self, which: str) -> None:
+        """The step's tail -- `which` = "all", or its "text" / "img" half (early text) -- on the current stream: as a captured
+        graph per learning rate when the collectives are captured (N > 1 on RCCL), else as plain launches."""
         tail = None
         if self.use_graph and getattr(self, "_graph_collectives", False) and self._steps > 0:
-            tail = self._tail_graphs.get(self.lr)               # the rate is a kernel argument: one small graph per rate
+            key = (self.lr, which)                              # the rate is a kernel argument: one small graph per rate
+            tail = self._tail_graphs.get(key)
             if tail is None:
                 try:
                     tail = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(tail, capture_error_mode="thread_local"):
-                        self._tail()
+                        self._tail(which)
                     if len(self._tail_graphs) >= 64:   # a schedule that changes the rate every step: keep the cache bounded
                         self._tail_graphs.clear()
-                    self._tail_graphs[self.lr] = tail
+                    self._tail_graphs[key] = tail
                 except Exception as ex:             # noqa: BLE001
                     print(f"[rpo_amd] capturing the step's tail failed ({type(ex).__name__}: {ex}); it stays eager")
                     self._graph_collectives, tail = False, None
@@ -292,24 +325,30 @@ class RPO:
         if tail is not None:
             tail.replay()
         else:
-            self._tail()
-        self._steps += 1
-        eng.params_version += 1
-        eng.text_f_version = -1
-        return eng.loss
+            self._tail(which)
 
-    def _tail(self) -> None:
-        """What follows the two backward chains: the all-reduce of what is still local, then the fused SGD step."""
+    def _tail(self, which: str = "all") -> None:
+        """What follows the backward chains: the all-reduce of what is still local, then the fused SGD step -- over the
+        whole flat buffer [text | img], or over one half of it (early text: the text half on the side stream behind the
+        text backward, whose all-reduce _replay has already issued; the image half on the main stream)."""
         eng, oc = self.engine, self.optim_cfg
-        if self.use_graph and self._split_collective and not self._joint_bwd:
-            self.sync.all_reduce_sum(eng.g_img_flat)            # (g_text went out behind the text backward, _replay)
+        nt = eng.g_text_flat.numel()
+        if which == "text":
+            sl = slice(0, nt)
+        elif which == "img":
+            sl = slice(nt, None)
+            self.sync.all_reduce_sum(eng.g_img_flat)
         else:
-            self.sync.all_reduce_sum(eng.grads)
+            sl = slice(None)
+            if self.use_graph and self._split_collective and not self._joint_bwd:
+                self.sync.all_reduce_sum(eng.g_img_flat)        # (g_text went out behind the text backward, _replay)
+            else:
+                self.sync.all_reduce_sum(eng.grads)
         if self.amp:
             ops.sgd_step_guarded(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
                                  self.sync.grad_scale, first_step=(self._steps == 0), found_inf=self._found_inf)
         else:
-            ops.sgd_step(eng.params, eng.grads, eng.mom, self.lr, oc.momentum, oc.weight_decay,
+            ops.sgd_step(eng.params[sl], eng.grads[sl], eng.mom[sl], self.lr, oc.momentum, oc.weight_decay,
                          self.sync.grad_scale, first_step=(self._steps == 0))
 
     def update_lr(self) -> None:
@@ -319,6 +358,7 @@ class RPO:
     def check_finite(self) -> None:
         """NaN / Inf scan of the step's outputs (the reference's `set_detect_anomaly(True)`, trainers/rpo.py:288)."""
         eng = self.engine
+        self._join_side()
         bad = [n for n, t in (("loss", eng.loss), ("logits", eng.logits[:self.batch_size]), ("grad text_prompt", eng.g_text),
                               ("grad img_prompt", eng.g_img), ("prompts", eng.params)) if not bool(torch.isfinite(t).all())]
         if bad:
@@ -332,7 +372,14 @@ class RPO:
 
     # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
     @torch.no_grad()
+    def _join_side(self) -> None:
+        """Early text: the next step's text forward may still be running on the side stream; whatever reads or writes the
+        prompts or the text tower's buffers from the current stream goes behind it."""
+        if getattr(self, "_early_text", False) and self._graph:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_text_fwd)
+
     def model_inference(self, image) -> torch.Tensor:
+        self._join_side()
         with torch.cuda.device(self.device):
             if isinstance(image, (list, tuple)):                # decoded uint8 images: resize + center crop + normalize
                 image = self.transform(False)(image)
@@ -355,6 +402,7 @@ class RPO:
         `epoch`.  Dassl writes `model-best.pth.tar` alone when a validation result improves; `after_epoch_eval` here
         also keeps the numbered file it is a copy of."""
         epoch = self.epoch if epoch is None else epoch
+        self._join_side()
         ck = checkpoint_dict(self.model.prompt_learner.state_dict(), epoch, self.engine.mom, self.optim_cfg,
                              self.lr, self._steps, self.cfg.K * self.cfg.d_t, val_result)
         return write_checkpoint(directory, ck, epoch, is_best)
@@ -381,6 +429,7 @@ class RPO:
         for k in ("token_prefix", "token_suffix"):              # :348-352
             sd.pop(k, None)
         print(f'Loading weights to prompt_learner from "{model_path}" (epoch = {ck["epoch"]})')
+        self._join_side()
         with torch.no_grad():                                   # load_state_dict(strict=False), :357
             for name, p in self.model.prompt_learner.named_parameters():
                 if name in sd:

@@ -175,6 +175,37 @@ def test_f16_mode_matches_reference_golden(tag):
     assert (logits.argmax(-1) == g["logits"].argmax(-1)).all()
 
 
+@pytest.mark.parametrize("early", ["0", "1"])
+def test_early_text_forward_changes_nothing(early, monkeypatch, tmp_path):
+    """RPO_EARLY_TEXT (on by default at small batches): the next step's text forward launched behind this step's text
+    backward + text SGD.  Same bits as eager launches over steps that include an epoch boundary (new learning rate), an
+    eval call between two steps and a checkpoint reload (prompts changed from outside: the early features are stale)."""
+    from rpo_amd.trainer import RPO
+    monkeypatch.setenv("RPO_EARLY_TEXT", early)
+    tag = "d2_k8_b3"
+    cfg, sd, toks, tp, ip, image, label = workload(tag)
+    B = image.shape[0]
+    outs = []
+    for use_graph in (False, True):
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=2, use_graph=use_graph, prompts=(tp, ip))
+        rec = []
+        for step in range(7):
+            batch = {"img": torch.from_numpy(synth.images(cfg, B, seed=50 + step)),
+                     "label": torch.from_numpy(synth.labels(cfg, B, seed=60 + step))}
+            rec.append(tr.forward_backward(batch)["loss"])
+            if step == 2:
+                rec.append(tr.model_inference(batch["img"].cuda()).float().cpu().numpy().tobytes())
+            if step == 3:
+                tr.save_model(str(tmp_path / f"g{int(use_graph)}"), epoch=1)
+            if step == 5:
+                tr.load_model(str(tmp_path / f"g{int(use_graph)}"), epoch=1)
+        if use_graph:
+            assert tr._early_text == (early == "1")
+        outs.append((rec, tr.engine.params.clone()))
+    assert outs[0][0] == outs[1][0], "early text forward changed a loss / the eval logits"
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("act", [torch.float32, torch.bfloat16, torch.float16])
 def test_graph_replay_equals_eager(act):
     from rpo_amd.trainer import RPO
