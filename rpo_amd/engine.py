@@ -104,6 +104,10 @@ class Engine:
         # / 0.6 % (same file).
         big = max_batch * (cfg.n_frozen + cfg.K) >= 6000
         self._ws_text_cfg = int(os.environ.get("RPO_WS_TEXT_CFG", "220" if big else "0"))
+        # ... and the text BACKWARD, which runs beside the image backward's small launches instead of beside one-round
+        # kernels, on 32x64 tiles there: -0.3 .. -0.4 % in 8 of 8 alternating rounds on two boxes; at batch 4 / 8 and for
+        # ViT-L/14 the kernel's choice stays (+0.9 / +0.7 / +0.4 % otherwise) -- same file.
+        self._ws_text_cfg_bwd = int(os.environ.get("RPO_WS_TEXT_CFG_BWD", os.environ.get("RPO_WS_TEXT_CFG", "120" if big else "0")))
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -845,7 +849,7 @@ class Engine:
         ops.reduce_groups(T["dxa"], self.g_text, n)
 
     def _text_backward(self) -> None:
-        self._ws_cfg = self._ws_text_cfg
+        self._ws_cfg = self._ws_text_cfg_bwd
         try:
             self._text_backward_()
         finally:
