@@ -107,6 +107,9 @@ class Engine:
         # ... and the text BACKWARD, which runs beside the image backward's small launches instead of beside one-round
         # kernels, on 32x64 tiles there: -0.3 .. -0.4 % in 8 of 8 alternating rounds on two boxes; at batch 4 / 8 and for
         # ViT-L/14 the kernel's choice stays (+0.9 / +0.7 / +0.4 % otherwise) -- same file.
+        # A/B knob: per-GEMM geometry of the text tower, e.g. RPO_WS_TEXT_TILES="proj=120,dfc=220" (q, out, fc, proj: forward;
+        # dproj, dfc, dq: backward) on top of the two defaults above
+        self._text_tiles = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("RPO_WS_TEXT_TILES", "").split(",") if kv))
         self._ws_text_cfg_bwd = int(os.environ.get("RPO_WS_TEXT_CFG_BWD", os.environ.get("RPO_WS_TEXT_CFG", "120" if big else "0")))
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
@@ -185,6 +188,9 @@ class Engine:
             both[dst].view(-1).copy_(pw.data)
             self._wsp[(both[src].data_ptr(), (d, d))] = ops.PackedWeight(both[dst].view(-1), d, d)
         return dict(w_out_t=both[1], w_q_t=both[0], w_oq_t=both)
+
+    def _tt(self, name: str) -> dict:
+        return {"tile_config": self._text_tiles[name]} if name in self._text_tiles else {}
 
     def _oq_hint(self, blk: _Block, fold_out: bool) -> torch.Tensor:
         if not self.use_ws:
@@ -407,7 +413,7 @@ class Engine:
             # GEMMs leave the 16-bit copy of their result in ht and its row statistics in st
             if fold and l > 0:
                 self._gemm(self.ht, blk.w_in_ln[:dt], self.qt[l], EPI_LN_BIAS, bias=blk.b_in_ln[:dt], ln_stats=st,
-                            ln_colsum=blk.s_in[:dt], prefetch=blk.w_out if pf else None)
+                            ln_colsum=blk.s_in[:dt], prefetch=blk.w_out if pf else None, **self._tt("q"))
             else:
                 ops.layernorm_fwd(self.xt[l], blk.ln1_w, blk.ln1_b, self.ht)
                 self._gemm(self.ht, blk.w_in[:dt], self.qt[l], EPI_BIAS, bias=blk.b_in[:dt],
@@ -416,18 +422,18 @@ class Engine:
                               causal=False, scale=SCALE)
             prod = dict(out2=self.ht, ln_stats=st) if fold else {}
             self._gemm(self.att_t, blk.w_out, self.xtm[l], EPI_BIAS_RESID, bias=blk.b_out, resid=self.xt[l], **prod,
-                        prefetch=(blk.w_fc_ln if fold else blk.w_fc) if pf else None)
+                        prefetch=(blk.w_fc_ln if fold else blk.w_fc) if pf else None, **self._tt("out"))
             if fold:
                 self._gemm(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                             aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc,
-                            prefetch=blk.w_proj if pf else None)
+                            prefetch=blk.w_proj if pf else None, **self._tt("fc"))
             else:
                 ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
                 self._gemm(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
                             aux=self.ut[l] if train else None, aux_row0=0, prefetch=blk.w_proj if pf else None)
             prod = dict(out2=self.ht, ln_stats=st) if (fold and l < last) else {}
             self._gemm(self.gt, blk.w_proj, self.xt[l + 1], EPI_BIAS_RESID, bias=blk.b_proj, resid=self.xtm[l], **prod,
-                        prefetch=nxt_q(l))
+                        prefetch=nxt_q(l), **self._tt("proj"))
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
         self._gemm(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 
@@ -644,10 +650,12 @@ class Engine:
 
     # ------------------------------------------------------------------ backward pieces
     def _rows_backward(self, blocks: List[_Block], x: List[torch.Tensor], xm: List[torch.Tensor],
-                       u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd, fold_out: bool = False) -> torch.Tensor:
+                       u: List[torch.Tensor], dxa, dxb, dxc, du, da, dq, dy, attn_bwd, fold_out: bool = False,
+                       tt: Optional[dict] = None) -> torch.Tensor:
         """Shared by both towers: dx (fp32, in dxa) holds dL/d(block output) on entry; on return the
         tensor holding dL/d(block-0 input).  dxc mirrors dx in the act dtype (GEMM A operand)."""
         pf = self._pf_chains
+        tc = lambda n: ({"tile_config": tt[n]} if (tt and n in tt) else {})       # (A/B knob: RPO_WS_TEXT_TILES)
         # split-K factors of the two fp32-output dX GEMMs (slabs summed in fixed order by rpo_layernorm_bwd).  On
         # rpo_gemm_ws the waves of a workgroup already split k four ways: d q-proj runs unsplit (one slab less for the
         # LayerNorm backward to read) and d c_fc in TWO.  Alone, four slabs are the faster launch at 768 rows (96x96 tiles
@@ -667,9 +675,9 @@ class Engine:
             #  the frozen rows' K / V of the block, 29 MB, named by this GEMM for the attention backward two kernels on:
             #  step 1.8 % SLOWER, 3.045 vs 2.992 ms; the saved QuickGELU operand u[l-1], named by the d q-proj GEMM: no
             #  effect, 2.875 vs 2.871 ms)
-            self._gemm(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None)  # d c_proj, d QuickGELU
+            self._gemm(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None, **tc("dproj"))  # d c_proj, d QuickGELU
             self._gemm(du, blk.w_fc_t, dy[:s_fc], EPI_NONE, split_k=s_fc,
-                       prefetch=self._oq_hint(blk, fold_out) if pf else None)                     # d c_fc
+                       prefetch=self._oq_hint(blk, fold_out) if pf else None, **tc("dfc"))        # d c_fc
             ops.layernorm_bwd(dy[:s_fc], xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
@@ -680,7 +688,7 @@ class Engine:
                 attn_bwd(l, da, dq)
             dyq = dy[0] if s_q == 1 else dy[:s_q]
             self._gemm(dq, blk.w_q_t, dyq, EPI_NONE, split_k=s_q,
-                       prefetch=blocks[l - 1].w_proj_t if (pf and l > 0) else None)   # d q-projection
+                       prefetch=blocks[l - 1].w_proj_t if (pf and l > 0) else None, **tc("dq"))   # d q-projection
             ops.layernorm_bwd(dyq, x[l], blk.ln1_w, dxb, dxa,
                               None if self.act == torch.float32 else dxc)
         return dxa
@@ -894,7 +902,7 @@ class Engine:
             dx = dxa
         else:
             dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
-                                     self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out)
+                                     self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out, tt=self._text_tiles)
         ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
 
     # ------------------------------------------------------------------ public
