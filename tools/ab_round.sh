@@ -6,5 +6,5 @@
 #   bash tools/ab_round.sh > gpurun_out/ab_round.txt
 for extra in "" "--model ViT-L/14 --batch 16" "--K 48" "--K 4" "--batch 4" "--batch 8" "--batch 16" "--batch 128" "--dtype f16"; do
   echo "## bench.py $extra"
-  python tools/ab_env.py --rounds 2 --steps 60 --extra "$extra" RPO_NO_WS=1,RPO_HIP_LIB=rpo_amd/build/ab/librpo_valu.so 2>&1 | grep -v amdgpu
+  python tools/ab_env.py --rounds 2 --steps 60 --extra "$extra" RPO_NO_WS=1,RPO_EARLY_TEXT=0,RPO_HIP_LIB=rpo_amd/build/ab/librpo_valu.so 2>&1 | grep -v amdgpu
 done
