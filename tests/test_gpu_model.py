@@ -361,6 +361,12 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["config"]["collectives_in_graph"] is False
     assert d2["config"]["final_loss"] == d["config"]["final_loss"]
+    # batch 4 runs the early text forward (text half of the tail captured on the side stream); the one-tail order that
+    # batch 32 per GPU uses -- the driver's scaling run -- must end at the same loss as well
+    r3 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, RPO_EARLY_TEXT="0"), cwd=root)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    d3 = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
+    assert d3["config"]["collectives_in_graph"] is True and d3["config"]["final_loss"] == d["config"]["final_loss"]
 
 
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
