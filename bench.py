@@ -500,6 +500,8 @@ def main() -> None:
     ap.add_argument("--model", default="ViT-B/16", choices=["ViT-B/16", "ViT-L/14"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-early-patch", action="store_true",
+                    help="do not name the next batch to step_async (its patch embed then opens its own step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trainer", choices=["rpo", "coop", "cocoop"], default="rpo",
                     help="rpo (default): the north-star step.  coop / cocoop: the sibling trainers of SURVEY 8f on the same "
@@ -560,13 +562,16 @@ def main() -> None:
     imgs = [torch.from_numpy(synth.images(cfg, args.batch, seed=1234 + 17 * i, rank=sync.rank)).to(dev) for i in range(pool)]
     labs = [torch.from_numpy(synth.labels(cfg, args.batch, seed=4321 + 17 * i, rank=sync.rank)).to(dev) for i in range(pool)]
 
+    # The loop names the next batch (already in HBM, like this one): its im2col + patch GEMM then run under this step's
+    # backward (RPO.step_async(next_image=...); one patch embed per step either way).  --no-early-patch: not.
+    nxt = (lambda i: None) if (args.no_early_patch or args.no_graph) else (lambda i: imgs[(i + 1) % pool])
     for i in range(args.warmup):
-        tr.step_async(imgs[i % pool], labs[i % pool])
+        tr.step_async(imgs[i % pool], labs[i % pool], nxt(i))
     sync.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = tr.step_async(imgs[i % pool], labs[i % pool])
+        loss = tr.step_async(imgs[i % pool], labs[i % pool], nxt(i))
     torch.cuda.synchronize()
     sync.barrier()
     torch.cuda.synchronize()
@@ -577,7 +582,7 @@ def main() -> None:
     host_steps = min(20, max(1, args.steps))
     th = time.perf_counter()
     for i in range(host_steps):
-        tr.step_async(imgs[i % pool], labs[i % pool])
+        tr.step_async(imgs[i % pool], labs[i % pool], nxt(i))
     host_s = time.perf_counter() - th
     torch.cuda.synchronize()
     sync.barrier()

@@ -38,6 +38,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -380,6 +384,9 @@ int rpo_probe_peak_copy(const void* src, void* dst, int64_t bytes, void* stream)
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 
 /* Measured-and-not-adopted experiments of rounds 3 / 4 (paired launches, the fused MLP launch, the persistent backward

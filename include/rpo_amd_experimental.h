@@ -8,6 +8,10 @@
 #ifndef RPO_AMD_EXPERIMENTAL_H
 #define RPO_AMD_EXPERIMENTAL_H
 
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -118,5 +122,8 @@ int rpo_chain_bwd_ok(const rpo_chain_bwd_args* args);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* RPO_AMD_EXPERIMENTAL_H */

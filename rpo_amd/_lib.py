@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librpo_hip.so")
 
 RPO_F32, RPO_BF16, RPO_F16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_QGELU_BWD, EPI_PATCH, EPI_LN_BIAS, EPI_LN_BIAS_QGELU = range(8)
+E_BADARG, E_SHAPE, E_DTYPE, E_ALIGN, E_WORKSPACE = -1, -2, -3, -4, -5      # include/rpo_amd.h RPO_E_*
 
 c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -58,7 +59,7 @@ class GemmArgs(C.Structure):
 
 
 class LnBwdArgs(C.Structure):
-    """struct rpo_ln_bwd_args (include/rpo_amd.h)."""
+    """struct rpo_ln_bwd_args (include/rpo_amd_experimental.h: the measured-slower experiments, -DRPO_EXPERIMENTAL build)."""
     _fields_ = [("dy", c_vp), ("lddy", c_i64), ("x", c_vp), ("ldx", c_i64), ("gamma", c_vp),
                 ("dres", c_vp), ("lddres", c_i64), ("dx", c_vp), ("lddx", c_i64),
                 ("dx_cast", c_vp), ("cast_dtype", c_i32), ("ldcast", c_i64),
@@ -66,7 +67,7 @@ class LnBwdArgs(C.Structure):
 
 
 class AttnBwdArgs(C.Structure):
-    """struct rpo_attn_bwd_args (include/rpo_amd.h)."""
+    """struct rpo_attn_bwd_args (include/rpo_amd_experimental.h: the measured-slower experiments, -DRPO_EXPERIMENTAL build)."""
     _fields_ = [("q_rows", c_vp), ("ldq", c_i64), ("k", c_vp), ("v", c_vp), ("ldkv", c_i64),
                 ("dx", c_vp), ("lddx", c_i64), ("w_out_t", c_vp), ("ldw", c_i64), ("dq", c_vp), ("lddq", c_i64),
                 ("groups", c_i32), ("H", c_i32), ("keys", c_i32), ("Kp", c_i32),
@@ -74,14 +75,14 @@ class AttnBwdArgs(C.Structure):
 
 
 class ChainLayer(C.Structure):
-    """struct rpo_chain_layer (include/rpo_amd.h)."""
+    """struct rpo_chain_layer (include/rpo_amd_experimental.h: the measured-slower experiments, -DRPO_EXPERIMENTAL build)."""
     _fields_ = [("w_proj_t", c_vp), ("w_fc_t", c_vp), ("w_out_t", c_vp), ("w_q_t", c_vp), ("aux", c_vp),
                 ("x_ln2", c_vp), ("x_ln1", c_vp), ("ln2_w", c_vp), ("ln1_w", c_vp),
                 ("q_rows", c_vp), ("k", c_vp), ("v", c_vp)]
 
 
 class ChainBwdArgs(C.Structure):
-    """struct rpo_chain_bwd_args (include/rpo_amd.h)."""
+    """struct rpo_chain_bwd_args (include/rpo_amd_experimental.h: the measured-slower experiments, -DRPO_EXPERIMENTAL build)."""
     _fields_ = [("layer", C.POINTER(ChainLayer)),
                 ("layers", c_i32), ("units", c_i32), ("Kp", c_i32), ("d", c_i32), ("H", c_i32), ("keys", c_i32),
                 ("dtype", c_i32),

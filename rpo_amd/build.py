@@ -18,7 +18,9 @@ LIB_EXP = os.path.join(HERE, "build", "librpo_hip_exp.so")
 SOURCES_EXP = SOURCES + ["chain.hip"]
 # preprocess.hip reproduces Pillow's double-precision coefficient math bit for bit: no FMA contraction
 EXTRA_FLAGS = {"preprocess.hip": ["-ffp-contract=off"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the dynamic symbol table holds the C ABI of include/rpo_amd.h (which pushes default visibility
+# around its declarations) and nothing else -- no mangled helpers, no kernel host stubs (tests/test_host_logic.py)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -59,7 +61,8 @@ def build_library(force: bool = False, verbose: bool = False, experimental: bool
 
     with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}",
+                        *objs, "-o", lib],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -188,12 +188,14 @@ class CoOp:
               "scheduler": {"last_epoch": int(epoch)}, "val_result": val_result, "steps": int(self._steps)}
         return write_checkpoint(directory, ck, epoch, is_best)
 
-    def load_model(self, directory: str, epoch: Optional[int] = None) -> None:
+    def load_model(self, directory: str, epoch: Optional[int] = None) -> Optional[dict]:
         """trainers/coop.py:283-325: `model-best.pth.tar` unless an epoch is named; token_prefix / token_suffix are
-        dropped (:315-320: they belong to the class names the checkpoint was trained on); load_state_dict(strict=False)."""
+        dropped (:315-320: they belong to the class names the checkpoint was trained on); load_state_dict(strict=False).
+        Returns the checkpoint dict it read (None where the reference skips: no directory) -- for `resume_model`; nothing
+        of it is kept on the trainer."""
         if not directory:
             print("Note that load_model() is skipped as no pretrained model is given")
-            return
+            return None
         model_file = "model-best.pth.tar" if epoch is None else f"model.pth.tar-{epoch}"
         model_path = os.path.join(directory, "prompt_learner", model_file)
         if not os.path.exists(model_path):
@@ -212,15 +214,16 @@ class CoOp:
         # else): optimiser state, epoch and learning rate stay what they were -- loading a finished model-best file and
         # training on must not start at the cosine's last rate with stale momentum (advisor, round 4).  Resuming a run is
         # `resume_model` below (Dassl's resume_model_if_exist).
-        self._ckpt = ck
         self._graph = None
+        return ck
 
     def resume_model(self, directory: str, epoch: Optional[int] = None) -> int:
         """Dassl's `resume_model_if_exist` for this trainer: `load_model` plus the optimiser's momentum buffers, the epoch
         and the learning rate of the checkpoint.  Returns the epoch to continue from.  A checkpoint whose momentum does
         not match the trained tensors (another n_ctx / CSC setting) is refused rather than half-applied."""
-        self.load_model(directory, epoch)
-        ck = self._ckpt
+        ck = self.load_model(directory, epoch)
+        if ck is None:
+            raise ValueError("resume_model needs a checkpoint directory (load_model skipped: nothing was loaded)")
         params = list(self.model.prompt_learner.named_parameters())
         st = (ck.get("optimizer") or {}).get("state") or {}
         if st:

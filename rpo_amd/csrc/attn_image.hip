@@ -302,6 +302,131 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
   }
 }
 
+// ---- forward, 16-bit storage, round 6: the key loop with less VALU around its 8 MFMAs -----------------------------------
+// The online-softmax loop is bound by VALU issue (~95 VALU instructions per key tile, 17 of them
+// quarter-rate v_exp, around 8 MFMAs; two to four waves share a SIMD).  Three cuts, none of which touches what is summed:
+//  * LAZY RESCALE: the running maximum m is a reference point, not a quantity of the result -- any m with
+//    (row max - m) * scale * log2(e) in [0, TAU] gives the same softmax up to rounding.  m is moved (and l and the
+//    output tile rescaled: 18 multiplies + one v_exp) only when SOME row of the wave has outgrown it by more than TAU = 8
+//    (P <= 256: exact in bf16 / f16 relative precision, far from f16's 65504).  The first key tile always moves it
+//    (m = -inf), later tiles almost never do.
+//  * THE PARTIAL KEY TILE (N = 197 = 6 x 32 + 5; 257 = 8 x 32 + 1) is peeled: by the C/D map a lane's registers 4g .. 4g+3
+//    are key offsets 8g + 4 half + {0..3}, so with rem valid keys only G = ceil(rem / 8) register groups are live -- the
+//    exps, sums and conversions of the others and the P.V MFMAs of a 16-key half without live keys are not issued
+//    (rem = 5: 4 of 16 v_exp, 2 of 4 P.V MFMAs).  Key tiles past N (N < 32 (NT - 1)) are skipped.
+//  * the scale-and-subtract and the row sum as packed fp32 (RPO_ATTN_PK; scalar without).
+constexpr float ATTN_TAU = 8.0f;
+
+template <typename T>
+__device__ __forceinline__ void lazy_rescale(float tm, float c, float& m, float& mc, float& l, f32x16_t (&o)[2]) {
+  if (__any((tm - m) * c > ATTN_TAU)) {            // wave-uniform; (tm - m) = +inf on the first tile
+    const float mn = fmaxf(m, tm);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);     // m = -inf: 0 (o and l are 0 there); m = mn: 1
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    m = mn;
+    mc = mn * c;
+  }
+}
+
+// p[r] = exp2(s[r] * c - mc) for r < NR (a multiple of 4), returns their sum
+template <int NR>
+__device__ __forceinline__ float exp_regs(const f32x16_t& s, float (&p)[16], float c, float mc) {
+#ifdef RPO_ATTN_PK
+  const f32x2_t cc = {c, c}, nm = {-mc, -mc};
+  f32x2_t acc = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < NR; r += 2) {
+    f32x2_t x = {s[r], s[r + 1]};
+    x = __builtin_elementwise_fma(x, cc, nm);
+    const f32x2_t e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+    p[r] = e.x; p[r + 1] = e.y;
+    acc += e;
+  }
+  return acc.x + acc.y;
+#else
+  float l = 0.f;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc)); l += p[r]; }
+  return l;
+#endif
+}
+
+// one FULL key tile (all 32 keys valid)
+template <typename T, int NT>
+__device__ __forceinline__ void fwd_tile_full(const char* ks, const char* vs, int t, const RowFrag<T>& qf, float c,
+                                              float& m, float& mc, float& l, f32x16_t (&o)[2], int l31, int half) {
+  const f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31, half);
+  float tm = fmaxf(sc[0], sc[1]);
+#pragma unroll
+  for (int r = 2; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+  tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+  lazy_rescale<T>(tm, c, m, mc, l, o);
+  float p[16];
+  l += exp_regs<16>(sc, p, c, mc);
+  const int lane = l31 + 32 * half;
+#pragma unroll
+  for (int g2 = 0; g2 < 2; ++g2) {
+    const bf16x8_t b = pack8<T>(p + 8 * g2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16);
+      o[dt] = mfma16<T>(a, b, o[dt]);
+    }
+  }
+}
+
+// the PARTIAL key tile: rem = N - 32 t valid keys, G = ceil(rem / 8) live register groups of four (wave-uniform branches:
+// one code path for every G -- four template instances of it spilled 35 registers around the switch)
+template <typename T, int NT>
+__device__ __forceinline__ void fwd_tile_tail(const char* ks, const char* vs, int t, int rem, const RowFrag<T>& qf, float c,
+                                              float& m, float& mc, float& l, f32x16_t (&o)[2], int l31, int half) {
+  f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31, half);      // (K rows >= N are zero in LDS: finite scores)
+  const int G = (rem + 7) >> 3;
+  float tm = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < G) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j, off = j + 8 * g + 4 * half;
+        sc[r] = off < rem ? sc[r] : -INFINITY;
+        tm = fmaxf(tm, sc[r]);
+      }
+    }
+  }
+  tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                      // finite: offset 0 is valid and belongs to half 0
+  lazy_rescale<T>(tm, c, m, mc, l, o);
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < G) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                            // exp2(-inf) = 0 for the masked offsets of the last group
+        p[4 * g + j] = __builtin_amdgcn_exp2f(fmaf(sc[4 * g + j], c, -mc));
+        l += p[4 * g + j];
+      }
+    }
+  }
+  const int lane = l31 + 32 * half;
+#pragma unroll
+  for (int g2 = 0; g2 < 2; ++g2) {
+    if (2 * g2 < G) {
+      const bf16x8_t b = pack8<T>(p + 8 * g2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16);
+        o[dt] = mfma16<T>(a, b, o[dt]);
+      }
+    }
+  }
+}
+
 // ---- forward ---------------------------------------------------------------------------
 template <typename T, int NT, bool TWO_PASS = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
@@ -448,6 +573,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
         contract_keys<T, NT>(vs, t, sc, o, l31v, half);
       }
     } else
+#ifndef RPO_ATTN_OLD_LOOP           // (A/B build: the round-2..5 loop below for the 16-bit modes too)
+    if constexpr (sizeof(T) == 2) {
+      // round 6 (see fwd_tile_full): lazy rescale, peeled partial key tile, key tiles past N skipped
+      const float c = scale * LOG2E;
+      float mc = 0.f;
+      const int nfull = min(N >> 5, NT), rem = N - 32 * nfull;
+#pragma unroll 1
+      for (int t = 0; t < nfull; ++t) fwd_tile_full<T, NT>(ks, vs, t, qf, c, m, mc, l, o, l31v, half);
+      if (rem > 0 && nfull < NT) fwd_tile_tail<T, NT>(ks, vs, nfull, rem, qf, c, m, mc, l, o, l31v, half);
+    } else
+#endif
 #pragma unroll 1
     for (int t = 0; t < NT; ++t) {
       // (issuing the score tile of key tile t+1 before the softmax arithmetic of tile t -- one more live tile, 118 VGPRs --

@@ -552,6 +552,7 @@ extern "C" int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, con
 // bias[b] = linear2(relu(linear1(f[b] / |f[b]|))): vis_dim -> vis_dim / 16 -> ctx_dim, one workgroup per image; the
 // normalised feature and the hidden activation are kept for the backward.  fp32 throughout (the reference's fp16 branch
 // halves the meta-net; fp32 is its PREC = fp32 / amp behaviour).
+namespace {
 __global__ __launch_bounds__(256) void metanet_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w1,
                                                           const float* __restrict__ b1, const float* __restrict__ w2,
                                                           const float* __restrict__ b2, float* fn, float* hid,
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(256) void metanet_bwd_kernel(const float* __restric
     g_b1[j] = a;
   }
 }
+}  // namespace
 
 extern "C" int rpo_metanet_fwd(const float* img_f, const float* w1, const float* b1, const float* w2, const float* b2,
                                float* f_norm, float* hidden, float* bias, int B, int e, int h, int d, void* stream) {

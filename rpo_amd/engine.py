@@ -192,9 +192,11 @@ class Engine:
     def _tt(self, name: str) -> dict:
         return {"tile_config": self._text_tiles[name]} if name in self._text_tiles else {}
 
-    def _oq_hint(self, blk: _Block, fold_out: bool) -> torch.Tensor:
+    def _oq_hint(self, blk: _Block, fold_out: bool, ws: bool = True) -> torch.Tensor:
         if not self.use_ws:
             return blk.w_oq_t
+        if not ws:                                  # a chain on rpo_gemm_nt reads the two row-major matrices (slots 0-1)
+            return blk.w_oq_t[0:2]
         return blk.w_oq_t[1:3] if fold_out else blk.w_oq_t[2:4]
 
     def _ws_reg(self, w: Optional[torch.Tensor]) -> None:
@@ -219,12 +221,18 @@ class Engine:
             if ok is None:
                 ok = self._ws_okc[key] = (M < 2048 and ops.gemm_ws_ok(M, pw.N, pw.K, self.act, out.dtype, epilogue, split, key[-1]))
             if ok:
-                if self._ws_cfg and "tile_config" not in kw:          # (the text tower's geometry: see __init__)
-                    kw["tile_config"] = self._ws_cfg
-                pf = kw.get("prefetch")
+                kws = dict(kw)
+                if self._ws_cfg and "tile_config" not in kws:         # (the text tower's geometry: see __init__)
+                    kws["tile_config"] = self._ws_cfg
+                pf = kws.get("prefetch")
                 if pf is not None:
-                    kw["prefetch"] = self._wsp.get((pf.data_ptr(), tuple(pf.shape)), pf)
-                return ops.gemm_ws(a, pw, out, epilogue, **kw)
+                    kws["prefetch"] = self._wsp.get((pf.data_ptr(), tuple(pf.shape)), pf)
+                # the cached verdict covers sizes / dtypes / epilogue / split only; what it does not see (a 96-column
+                # statistics group, hi / lo residual halves, row units, a forced geometry that does not fit) makes the
+                # kernel answer RPO_E_SHAPE with nothing enqueued -- then the row-major weight goes to rpo_gemm_nt
+                if ops.gemm_ws_try(a, pw, out, epilogue, **kws):
+                    return out
+                kw.pop("tile_config", None)                            # (an rpo_gemm_ws geometry code means nothing to rpo_gemm_nt)
         return ops.gemm_nt(a, w, out, epilogue, **kw)
 
     def _pack(self, sd, tokens) -> None:
@@ -252,8 +260,9 @@ class Engine:
         self.text_proj_t, self.text_proj = self._act(tp.t()), self._act(tp)
         for w in (self.img_proj_t, self.img_proj, self.text_proj_t, self.text_proj):
             self._ws_reg(w)
-        # small batches (config 1: batch 4): the WHOLE image forward is a small-M problem -- B x (N + K) < 2048 rows, no
-        # one-round geometry -- so every block's forward weights get a packed twin too (RPO_WS_SMALL=0: not).  B x (N + K) < 1024.
+        # small batches (config 1: batch 4): below 1024 image token rows -- B x (N + K) < 1024 -- the WHOLE image forward is a
+        # small-M problem with no one-round geometry, so every block's forward weights get a packed twin too
+        # (RPO_WS_SMALL=0: not; from 1024 rows on the 64x128 / 128x128 tiles win).
         self.ws_small = (self.use_ws and self.max_batch * (cfg.n_frozen + cfg.K) < 1024 and os.environ.get("RPO_WS_SMALL", "1") != "0")
         if self.ws_small:
             for blk in self.vis:
@@ -437,16 +446,27 @@ class Engine:
         ops.layernorm_fwd(self.xt[-1], self.ln_final[0], self.ln_final[1], self.y_final)   # rpo.py:183
         self._gemm(self.y_final, self.text_proj_t, self.text_f, EPI_NONE)                 # rpo.py:191
 
-    def _image_forward(self, image: torch.Tensor, train: bool, full_last: bool = False) -> None:
+    def _patch_embed(self, image: torch.Tensor) -> None:
+        """conv1 as im2col + GEMM, positional embedding added in the epilogue (trainers/rpo.py:198-202): the PATCH rows of
+        x_pre.  Depends on the batch alone -- not on the prompts -- so the trainer may run it for the NEXT batch while
+        this step's backward is still running (RPO.step_async(next_image=...)): the only other reader of x_pre after the
+        first launch of the image forward is the last LayerNorm backward, which reads its prompt rows."""
+        cfg = self.cfg
+        B = image.shape[0]
+        R = B * (cfg.n_frozen + cfg.K)
+        ops.im2col_patches(image, self.im2col[:B * cfg.n_patches], cfg.patch)
+        ops.gemm_nt(self.im2col[:B * cfg.n_patches], self.conv_w, self.x_pre[:R], EPI_PATCH, resid=self.pos,
+                    group=cfg.n_patches,                                               # rpo.py:198-202
+                    prefetch=self.vis[0].w_in if (self._pf_chains and len(self.vis)) else None)
+
+    def _image_forward(self, image: torch.Tensor, train: bool, full_last: bool = False, patch_done: bool = False) -> None:
         cfg = self.cfg
         B, N, K, dv, H = image.shape[0], cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
         Rf, Rp = B * N, B * K
         R = Rf + Rp
         x_pre = self.x_pre[:R]
-        ops.im2col_patches(image, self.im2col[:B * cfg.n_patches], cfg.patch)
-        ops.gemm_nt(self.im2col[:B * cfg.n_patches], self.conv_w, x_pre, EPI_PATCH, resid=self.pos,
-                    group=cfg.n_patches,                                               # rpo.py:198-202
-                    prefetch=self.vis[0].w_in if (self._pf_chains and len(self.vis)) else None)
+        if not patch_done:                      # (patch_done: _patch_embed(image) has already been enqueued for this batch)
+            self._patch_embed(image)
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
         # CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch
         ops.img_embed_norm(x_pre, self.cls, self.pos, self.img_prompt, self.ln_pre[0], self.ln_pre[1], self.x[0][:R],
@@ -477,9 +497,9 @@ class Engine:
         u_out, u_proj = (units if which == "all" else None), (units if which in ("all", "c_proj") else None)
         if small:
             u_out = u_proj = None
-        grps = self._stats_group.get((B, split))
+        grps = self._stats_group.get((B, split, small))
         if grps is None:
-            grps = self._stats_group[(B, split)] = ((ops.gemm_stats_group(Mw, dv, dv, self.act, u_out),
+            grps = self._stats_group[(B, split, small)] = ((ops.gemm_stats_group(Mw, dv, dv, self.act, u_out),
                                                      ops.gemm_stats_group(Mw, dv, 4 * dv, self.act, u_proj)) if fold else (64, 64))
         g_out, g_proj = grps                 # statistics written by out-proj (read by c_fc) / by c_proj (read by in-proj)
         # Residual stream as 16-bit hi / lo halves (rpo_gemm_args.resid_hi ...): where both residual GEMMs of a block run on
@@ -662,9 +682,12 @@ class Engine:
         # x 4 = one round of the CUs: 9.0 vs 10.7 us, profiles/r05_bench_gemm_ws.txt), but in the step two slabs win
         # (-0.85 % step time, three alternating pairs, profiles/r05_ab_ws_splits.txt): half the workgroups beside the text
         # tower and half the slab bytes for the LayerNorm backward behind it.
-        d = blocks[0].w_q_t.shape[0] if blocks else 0
-        s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not self.use_ws else (2, 1)
-        if self.use_ws and "RPO_WS_SPLITS" in os.environ:             # A/B: "FCxQ" (step-level tuning, tools/ab_env.py)
+        # (whether rpo_gemm_ws really takes this chain: _gemm sends M >= 2048 rows -- the text tower from 86 classes on at
+        #  K = 24, the image tower from batch 86 on -- to rpo_gemm_nt's tiles, which keep their own step-tuned split factors
+        #  and read the row-major d x d operands)
+        ws = self.use_ws and dxa.shape[0] < 2048
+        s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not ws else (2, 1)
+        if ws and "RPO_WS_SPLITS" in os.environ:             # A/B: "FCxQ" (step-level tuning, tools/ab_env.py)
             s_fc, s_q = (int(v) for v in os.environ["RPO_WS_SPLITS"].split("x"))
         for l in reversed(range(len(blocks))):
             blk = blocks[l]
@@ -677,7 +700,7 @@ class Engine:
             #  effect, 2.875 vs 2.871 ms)
             self._gemm(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None, **tc("dproj"))  # d c_proj, d QuickGELU
             self._gemm(du, blk.w_fc_t, dy[:s_fc], EPI_NONE, split_k=s_fc,
-                       prefetch=self._oq_hint(blk, fold_out) if pf else None, **tc("dfc"))        # d c_fc
+                       prefetch=self._oq_hint(blk, fold_out, ws) if pf else None, **tc("dfc"))    # d c_fc
             ops.layernorm_bwd(dy[:s_fc], xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc

@@ -159,6 +159,17 @@ def gemm_ws(a: torch.Tensor, w: PackedWeight, out: torch.Tensor, epilogue: int =
     return out
 
 
+def gemm_ws_try(a: torch.Tensor, w: PackedWeight, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> bool:
+    """`gemm_ws`, but a problem the kernel does not take (RPO_E_SHAPE: nothing was enqueued) returns False instead of
+    raising, so that the caller can issue rpo_gemm_nt on the row-major weight; every other error still raises."""
+    args = gemm_args(a, _WView(w), out, epilogue, **kw)
+    rc = int(_lib.load().rpo_gemm_ws(C.byref(args), _stream()))
+    if rc == _lib.E_SHAPE:
+        return False
+    check(rc, "rpo_gemm_ws")
+    return True
+
+
 def gemm_ws_ok(M: int, N: int, K: int, dtype: torch.dtype, out_dtype: torch.dtype, epilogue: int, split_k: int = 1,
                stats: bool = False) -> bool:
     """Does rpo_gemm_ws take this problem (rpo_gemm_ws_ok)?"""

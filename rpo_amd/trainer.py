@@ -202,6 +202,14 @@ class RPO:
         self._ev_text_fwd = torch.cuda.Event()
         self._ev_head = torch.cuda.Event()
         self._ev_text_bwd = torch.cuda.Event()
+        # EARLY PATCH EMBED (round 6): im2col + the patch GEMM of the NEXT batch depend on nothing this step computes
+        # (trainers/rpo.py:198-202: no prompt before :204), so when the caller names the next batch
+        # (step_async(next_image=...)) they run on the side stream behind the text backward -- under the tail of this
+        # step's image backward -- and the next step's image forward starts at img_embed_norm.  Captured on first use.
+        self._g_patch = self._g_img_fwd_np = None
+        self._ev_patch = torch.cuda.Event()
+        self._patch_tag = None                       # (data_ptr, version) of the batch whose patch rows are in x_pre
+        self._image_next = None
         # EARLY TEXT (round 5): the text tower's gradient is complete ~0.25 ms before the image tower's, and the next step's
         # text forward needs nothing but the updated text prompts -- so the text half of the SGD step runs on the side
         # stream right behind the text backward (and its all-reduce), and the NEXT step's text forward follows it there,
@@ -217,18 +225,83 @@ class RPO:
         self._early_text = ((want == "1" or (want is None and small)) and not self.amp and not self._joint_bwd
                             and self._bwd_parts == 1 and (not self.sync.enabled or self._split_collective))
         self._text_fwd_for = -1
+        # ONE GRAPH PER STEP (round 6, RPO_ONE_GRAPH=1): text fwd || image fwd -> head -> text bwd (+ its all-reduce) ||
+        # image bwd captured as ONE graph whose two branches fork and join through the side stream inside the capture,
+        # instead of five replays with host-enqueued events between them.  Not with early text / early patch embed /
+        # the paired or multi-part backward experiments (they reorder work ACROSS steps or streams).
+        self._g_step = None
+        if (os.environ.get("RPO_ONE_GRAPH") == "1" and not self._early_text and not self._joint_bwd and self._bwd_parts == 1
+                and (not self._split_collective or self._text_ar_in_graph or not self.sync.enabled)):
+            def whole():
+                main, side = torch.cuda.current_stream(), eng.side
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    eng._text_forward(train=True)
+                eng._image_forward(self._image, train=True)
+                main.wait_stream(side)
+                eng.head(B, self._label)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    eng._text_backward()
+                    if self._text_ar_in_graph:
+                        self.sync.all_reduce_sum(eng.g_text_flat)
+                eng._image_backward(B)
+                main.wait_stream(side)
+            try:
+                self._g_step = cap(whole)
+            except Exception as ex:                 # noqa: BLE001 -- a capture failure keeps the five-graph path
+                print(f"[rpo_amd] one-graph capture failed ({type(ex).__name__}: {ex}); five graphs per step")
+                self._g_step = None
+                torch.cuda.synchronize()
         self._graph = True
         torch.cuda.synchronize()
 
-    def _replay(self) -> None:
+    def _patch_graph(self, next_image: torch.Tensor):
+        """The early patch embed of `next_image` as a captured graph that reads the caller's buffer IN PLACE (one graph per
+        distinct buffer address, up to eight: a loader's ring of device buffers); beyond that the batch is copied into a
+        staging buffer with a graph of its own.  Also captures, once, the image forward that starts behind the patch rows."""
+        eng = self.engine
+        if self._g_img_fwd_np is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                eng._image_forward(self._image, train=True, patch_done=True)
+            self._g_img_fwd_np = g
+            self._g_patch = {}
+        src = next_image
+        if src.data_ptr() not in self._g_patch and len(self._g_patch) >= 8:
+            if self._image_next is None:
+                self._image_next = torch.zeros_like(self._image)
+            self._image_next.copy_(next_image, non_blocking=True)
+            src = self._image_next
+        g = self._g_patch.get(src.data_ptr())
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                eng._patch_embed(src)
+            self._g_patch[src.data_ptr()] = (g, src)          # (keeps the buffer alive as long as its graph)
+            torch.cuda.synchronize()
+        else:
+            g = g[0]
+        return g
+
+    def _replay(self, patch_ready: bool = False, g_patch=None) -> None:
         main, side = torch.cuda.current_stream(), self.engine.side
+        if self._g_step is not None and not patch_ready and g_patch is None:
+            self._g_step.replay()
+            return
         self._ev_fork.record(main)                  # inputs / updated prompts are ready
         if not (self._early_text and self._text_fwd_for == self.engine.params_version):
             side.wait_event(self._ev_fork)          # (early text: the previous step already ran this forward, see below)
             with torch.cuda.stream(side):
                 self._g_text_fwd.replay()
                 self._ev_text_fwd.record(side)
-        self._g_img_fwd.replay()
+        if patch_ready:                             # the previous step ran this batch's patch embed on the side stream
+            main.wait_event(self._ev_patch)
+            self._g_img_fwd_np.replay()
+        else:
+            self._g_img_fwd.replay()
         main.wait_event(self._ev_text_fwd)
         self._g_head.replay()
         if self._joint_bwd:
@@ -251,6 +324,9 @@ class RPO:
                 self._text_fwd_for = self.engine.params_version + 1     # (step_async bumps the version after the tail)
             else:
                 self._ev_text_bwd.record(side)
+            if g_patch is not None:                 # the NEXT batch's patch rows, behind the text chain
+                g_patch.replay()
+                self._ev_patch.record(side)
         if self._bwd_parts > 1:
             for st, ev, g in zip(self._part_streams, self._ev_parts, self._g_img_bwd_parts[1:]):
                 st.wait_event(self._ev_head)
@@ -280,19 +356,36 @@ class RPO:
             self.batch_idx += 1
         return summary
 
-    def step_async(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    def step_async(self, image: torch.Tensor, label: torch.Tensor, next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One optimisation step, nothing synchronised; returns the device loss scalar.  The caller's current
-        device must be this trainer's (kernels launch on the current device's streams)."""
+        device must be this trainer's (kernels launch on the current device's streams).
+        `next_image` (optional, graph path): the batch the NEXT call will pass as `image`, already on the device -- its
+        patch embedding then runs under this step's backward (see _capture).  Contract: the next call's `image` is that
+        same tensor, unmodified (checked by address + version counter; a mismatch just recomputes)."""
         eng, oc = self.engine, self.optim_cfg
         assert torch.cuda.current_device() == self.device.index, "set the trainer's device current (torch.cuda.set_device)"
         assert image.shape[0] == self.batch_size, "graph path needs the configured batch size"
-        if image.data_ptr() != self._image.data_ptr():
+        tag = (image.data_ptr(), image._version)
+        pending = self.use_graph and self._graph is not None and self._patch_tag is not None
+        patch_ready = pending and self._patch_tag == tag
+        if pending and not patch_ready:             # a promise that was not kept: this step's own patch embed goes behind it
+            torch.cuda.current_stream().wait_event(self._ev_patch)
+        self._patch_tag = None
+        if not patch_ready and image.data_ptr() != self._image.data_ptr():
             self._image.copy_(image, non_blocking=True)
         self._label.copy_(label, non_blocking=True)
         if self.use_graph:
             if self._graph is None:
                 self._capture()
-            self._replay()
+            patch_next = (next_image is not None and os.environ.get("RPO_EARLY_PATCH", "1") != "0"
+                          and not self._joint_bwd and self._bwd_parts == 1)
+            g_patch = None
+            if patch_next:
+                assert (next_image.shape == self._image.shape and next_image.dtype == torch.float32 and next_image.is_cuda
+                        and next_image.is_contiguous())
+                g_patch = self._patch_graph(next_image)
+                self._patch_tag = (next_image.data_ptr(), next_image._version)
+            self._replay(patch_ready, g_patch)
         else:
             eng.forward_backward(self._image, self._label)
         if self.amp and self._found_inf is None:
@@ -371,13 +464,20 @@ class RPO:
                 raise RuntimeError(f"{name}: a bounded spin gave up in or before step {self._steps}: the results are undefined")
 
     # -- evaluation (trainers/rpo.py:229-232 eval branch) -----------------------------------
-    @torch.no_grad()
     def _join_side(self) -> None:
-        """Early text: the next step's text forward may still be running on the side stream; whatever reads or writes the
-        prompts or the text tower's buffers from the current stream goes behind it."""
-        if getattr(self, "_early_text", False) and self._graph:
-            torch.cuda.current_stream(self.device).wait_event(self._ev_text_fwd)
+        """Early text / early patch embed: the next step's text forward or patch embed may still be running on the side
+        stream; whatever reads or writes the prompts, the text tower's buffers or the image tower's input buffers from
+        the current stream goes behind it (and a pending patch embed is forgotten: the next step computes its own)."""
+        if not self._graph:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_early_text", False):
+            cur.wait_event(self._ev_text_fwd)
+        if getattr(self, "_patch_tag", None) is not None:
+            cur.wait_event(self._ev_patch)
+            self._patch_tag = None
 
+    @torch.no_grad()
     def model_inference(self, image) -> torch.Tensor:
         self._join_side()
         with torch.cuda.device(self.device):

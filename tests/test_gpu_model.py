@@ -206,6 +206,66 @@ def test_early_text_forward_changes_nothing(early, monkeypatch, tmp_path):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("early_text", ["0", "1"])
+def test_early_patch_embed_changes_nothing(early_text, monkeypatch):
+    """step_async(next_image=...): the next batch's im2col + patch GEMM under this step's backward (side stream, behind the
+    text chain).  Same bits as eager launches, over a sequence that keeps the promise (next call's image IS next_image),
+    breaks it (another tensor; the named tensor modified in place afterwards), has an eval call between two steps (which
+    overwrites the image tower's input buffers) and more distinct buffers than the trainer keeps patch graphs for."""
+    from rpo_amd.trainer import RPO
+    monkeypatch.setenv("RPO_EARLY_TEXT", early_text)
+    cfg, sd, toks, tp, ip, image, label = workload("d2_k8_b3")
+    B = image.shape[0]
+    nb = 12
+    imgs = [torch.from_numpy(synth.images(cfg, B, seed=50 + i)).cuda() for i in range(nb)]
+    labs = [torch.from_numpy(synth.labels(cfg, B, seed=60 + i)).cuda() for i in range(nb)]
+    outs = []
+    for use_graph in (False, True):
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=10 ** 9, use_graph=use_graph, prompts=(tp, ip))
+        rec, used = [], 0
+        cur = [t.clone() for t in imgs]
+        for step in range(nb - 1):
+            promise = cur[step + 1]
+            if step == 4:
+                promise = cur[0]                                  # a promise that is not kept: the next call passes cur[5]
+            loss = tr.step_async(cur[step], labs[step], promise if use_graph else None)
+            if step == 6:
+                cur[7].mul_(0.5)                                  # the named buffer changes after it was named
+            rec.append(float(loss.item()))
+            if step == 2:
+                rec.append(tr.model_inference(cur[9]).float().cpu().numpy().tobytes())
+            if use_graph and step >= 1:
+                used += tr._patch_tag is not None
+        if use_graph:
+            assert used >= nb - 3 and tr._g_img_fwd_np is not None and len(tr._g_patch) <= 9
+        torch.cuda.synchronize()
+        outs.append((rec, tr.engine.params.clone()))
+    assert outs[0][0] == outs[1][0], "the early patch embed changed a loss / the eval logits"
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_one_graph_per_step_equals_eager(monkeypatch):
+    """RPO_ONE_GRAPH=1: the whole step -- both streams, fork and join inside the capture -- as one HIP graph."""
+    from rpo_amd.trainer import RPO
+    monkeypatch.setenv("RPO_ONE_GRAPH", "1")
+    monkeypatch.setenv("RPO_EARLY_TEXT", "0")
+    cfg, sd, toks, tp, ip, image, label = workload("d2_k8_b3")
+    B = image.shape[0]
+    outs = []
+    for use_graph in (False, True):
+        tr = RPO(cfg, sd, toks, None, "cuda:0", torch.bfloat16, batch_size=B, num_batches=2, use_graph=use_graph, prompts=(tp, ip))
+        ls = []
+        for step in range(5):
+            batch = {"img": torch.from_numpy(synth.images(cfg, B, seed=50 + step)),
+                     "label": torch.from_numpy(synth.labels(cfg, B, seed=60 + step))}
+            ls.append(tr.forward_backward(batch)["loss"])
+        if use_graph:
+            assert tr._g_step is not None, "the one-graph capture fell back"
+        outs.append((ls, tr.engine.params.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("act", [torch.float32, torch.bfloat16, torch.float16])
 def test_graph_replay_equals_eager(act):
     from rpo_amd.trainer import RPO

@@ -36,6 +36,32 @@ def test_library_exports_every_declared_symbol():
     assert b"shape" in _lib.load().rpo_error_string(-2)
 
 
+def test_dynamic_symbol_table_is_the_header_and_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: `nm -D` of the product library lists exactly the functions include/rpo_amd.h
+    declares -- no C++-mangled helpers, no kernel handles / host stubs, no toolchain bookkeeping symbols."""
+    import subprocess
+    from rpo_amd import _lib
+    from rpo_amd.build import build_library
+    build_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _header_functions(), sorted(set(exported) ^ set(_header_functions()))
+
+
+def test_integration_md_snippets_use_the_structs_real_field_names():
+    """INTEGRATION.md's Level-2 snippet builds a GemmArgs by keyword: every keyword must be a field of the struct (a wrong
+    name raises TypeError in ctypes -- round 5 shipped `a_dtype` / `c_dtype`)."""
+    from rpo_amd._lib import GemmArgs
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    calls = re.findall(r"GemmArgs\((.*?)\)\n", text, flags=re.S)
+    assert calls, "the GemmArgs(...) snippet is gone from INTEGRATION.md"
+    fields = {f[0] for f in GemmArgs._fields_}
+    for body in calls:
+        kws = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*=(?!=)", body)
+        assert kws and set(kws) <= fields, sorted(set(kws) - fields)
+        GemmArgs(**{k: 0 for k in kws})             # constructs
+
+
 def test_experiments_live_only_in_the_experimental_library():
     """include/rpo_amd_experimental.h: every entry point it declares is exported by the -DRPO_EXPERIMENTAL build and by
     that build alone -- the product library and the product header carry none of it."""
@@ -486,3 +512,15 @@ def test_mfma_busy_figure_is_in_one_clock_domain():
         lo, hi = sorted((res.get("mfma_busy_wall", 0.0), res.get("mfma_busy_lifetime", 1.0)))
         assert lo - 0.05 <= res["mfma_busy"] <= hi + 0.05, res
         assert res["met"] == (res["mfma_busy"] >= 0.70)
+
+
+def test_golden_manifest_matches_the_committed_fixtures():
+    """tests/golden/manifest_fullsize.json is the provenance record of the reference-generated fixtures: its byte counts
+    are those of the committed files (a regenerated fixture with a stale record was an advisor finding in round 5)."""
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    man = json.load(open(os.path.join(gold, "manifest_fullsize.json")))
+    for name, rec in man["cases"].items():
+        path = os.path.join(gold, f"ref_{name}.npz")
+        assert os.path.exists(path), path
+        assert os.path.getsize(path) == rec["bytes"], (name, os.path.getsize(path), rec["bytes"])
