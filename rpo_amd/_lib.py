@@ -160,6 +160,13 @@ EXPERIMENTAL_SIGNATURES = {
 }
 EXPERIMENTAL = os.environ.get("RPO_EXPERIMENTAL") == "1"
 
+
+def xenv(name: str, default: str = "0") -> str:
+    """Switch of a measured-slower EXPERIMENT: read only when RPO_EXPERIMENTAL=1 -- which also
+    selects the -DRPO_EXPERIMENTAL build of the library -- otherwise the default.  The default train step, the eval path
+    and the sibling trainers never take these branches."""
+    return os.environ.get(name, default) if EXPERIMENTAL else default
+
 _lib = None
 
 

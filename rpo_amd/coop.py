@@ -33,7 +33,7 @@ import torch
 from . import ops
 from .config import RPOConfig
 from .custom_clip import config_from_state_dict
-from .engine import Engine
+from .engine import Engine, make_engine
 from .trainer import OptimConfig, load_checkpoint_file, lr_at_epoch, write_checkpoint
 
 
@@ -99,7 +99,7 @@ class CoOpCustomCLIP:
         if cfg is None:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])     # one (unused) RPO prompt row per image
         self.cfg = cfg
-        self.engine = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        self.engine = make_engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
         if ctx is None and ctx_init is not None:
             csc = False                      # CTX_INIT wins over CSC, as in the reference (trainers/coop.py:72-80 vs :84)
         with torch.cuda.device(self.engine.dev):
@@ -321,7 +321,7 @@ class CoCoOpCustomCLIP:
         if cfg is None:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])
         self.cfg = cfg
-        self.engine = eng = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        self.engine = eng = make_engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
         e, dt = cfg.embed, cfg.d_t
         h = e // 16                                                          # vis_dim // 16 (:94)
         with torch.cuda.device(eng.dev):

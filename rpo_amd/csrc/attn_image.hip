@@ -194,12 +194,22 @@ template <> struct RowFrag<float> {
 };
 
 // one 32x32 tile:  D[i][q] = M[32t + i][:] . frag[q][:]   (M = K or V rows, row-major in LDS)
-template <typename T>
+// SW (16-bit): rows of 128 B without padding, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7) -- the layout an LDS-DMA
+// (lane-linear 1 KiB per wave instruction) can write; conflict-free for these reads as in gemm.hip
+template <typename T, bool SW = false>
 __device__ __forceinline__ f32x16_t tile_times_frag(const char* lds, int t, const RowFrag<T>& fr, int l31, int half) {
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2 && SW) {
+    const int row = 32 * t + l31, sw = (row >> 1) & 7;
+    const char* rowp = lds + row * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(rowp + (((2 * ks + half) ^ sw) << 4));
+      acc = mfma16<T>(a, fr.f[ks], acc);
+    }
+  } else if constexpr (sizeof(T) == 2) {
     const char* rowp = lds + (32 * t + l31) * 144 + half * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -302,89 +312,44 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
   }
 }
 
-// ---- forward, 16-bit storage, round 6: the key loop with less VALU around its 8 MFMAs -----------------------------------
-// The online-softmax loop is bound by VALU issue (~95 VALU instructions per key tile, 17 of them
-// quarter-rate v_exp, around 8 MFMAs; two to four waves share a SIMD).  Three cuts, none of which touches what is summed:
-//  * LAZY RESCALE: the running maximum m is a reference point, not a quantity of the result -- any m with
-//    (row max - m) * scale * log2(e) in [0, TAU] gives the same softmax up to rounding.  m is moved (and l and the
-//    output tile rescaled: 18 multiplies + one v_exp) only when SOME row of the wave has outgrown it by more than TAU = 8
-//    (P <= 256: exact in bf16 / f16 relative precision, far from f16's 65504).  The first key tile always moves it
-//    (m = -inf), later tiles almost never do.
+// ---- forward, 16-bit storage, round 6: the key loop ---------------------------------------------------------------------
+// What a wave does per key tile is one dependent chain (4 score MFMAs on one accumulator -> max -> cross-half exchange ->
+// exp -> rescale of the output tile -> 4 P.V MFMAs) and the workgroup's time is staging + NT of them
+// (profiles/r06_attn_timeline.txt: 4.3-8.9 k cycles of staging, 9.5-12 k of loop, with ONE or TWO workgroups on the CU alike).
 //  * THE PARTIAL KEY TILE (N = 197 = 6 x 32 + 5; 257 = 8 x 32 + 1) is peeled: by the C/D map a lane's registers 4g .. 4g+3
 //    are key offsets 8g + 4 half + {0..3}, so with rem valid keys only G = ceil(rem / 8) register groups are live -- the
 //    exps, sums and conversions of the others and the P.V MFMAs of a 16-key half without live keys are not issued
-//    (rem = 5: 4 of 16 v_exp, 2 of 4 P.V MFMAs).  Key tiles past N (N < 32 (NT - 1)) are skipped.
-//  * the scale-and-subtract and the row sum as packed fp32 (RPO_ATTN_PK; scalar without).
+//    (rem = 5: 4 of 16 v_exp, 2 of 4 P.V MFMAs); key tiles past N (N < 32 (NT - 1)) are skipped.  What is skipped is
+//    arithmetic on exact zeros (exp2(-inf) = 0, 0 x v, alpha = 1), so the result is BIT-IDENTICAL to the round-5 kernel.
+//  * -DRPO_ATTN_LAZY (A/B build, NOT the default): lazy rescale -- the running maximum m as a reference point that is moved
+//    (and l and the output tile rescaled: 18 multiplies + one v_exp) only when some row of the wave has outgrown it by more
+//    than TAU = 8 in log2 units.  Measured (profiles/r06_attn_variants.txt): kernel 15.6 vs 16.0 us, step -0.4 %; but the
+//    largest weight of a row is then no longer exactly 1.0 in the 16-bit P, and the op's max abs error grows 1.7x (bf16
+//    6.6e-3 vs 3.8e-3 on |out| <= 1.3; model-level logits error unchanged) -- not worth a looser op-level bound.
 constexpr float ATTN_TAU = 8.0f;
 
+// moves the running maximum m to cover this tile's row maximum tm; returns the factor the running sum / output carry
 template <typename T>
-__device__ __forceinline__ void lazy_rescale(float tm, float c, float& m, float& mc, float& l, f32x16_t (&o)[2]) {
-  if (__any((tm - m) * c > ATTN_TAU)) {            // wave-uniform; (tm - m) = +inf on the first tile
-    const float mn = fmaxf(m, tm);
-    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);     // m = -inf: 0 (o and l are 0 there); m = mn: 1
-    l *= alpha;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    m = mn;
-    mc = mn * c;
-  }
-}
-
-// p[r] = exp2(s[r] * c - mc) for r < NR (a multiple of 4), returns their sum
-template <int NR>
-__device__ __forceinline__ float exp_regs(const f32x16_t& s, float (&p)[16], float c, float mc) {
-#ifdef RPO_ATTN_PK
-  const f32x2_t cc = {c, c}, nm = {-mc, -mc};
-  f32x2_t acc = {0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < NR; r += 2) {
-    f32x2_t x = {s[r], s[r + 1]};
-    x = __builtin_elementwise_fma(x, cc, nm);
-    const f32x2_t e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-    p[r] = e.x; p[r + 1] = e.y;
-    acc += e;
-  }
-  return acc.x + acc.y;
-#else
-  float l = 0.f;
-#pragma unroll
-  for (int r = 0; r < NR; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc)); l += p[r]; }
-  return l;
+__device__ __forceinline__ float move_max(float tm, float scale, float& m, f32x16_t (&o)[2]) {
+#ifdef RPO_ATTN_LAZY
+  if (!__any((tm - m) * (scale * LOG2E) > ATTN_TAU)) return 1.0f;      // wave-uniform; (tm - m) = +inf on the first tile
 #endif
-}
-
-// one FULL key tile (all 32 keys valid)
-template <typename T, int NT>
-__device__ __forceinline__ void fwd_tile_full(const char* ks, const char* vs, int t, const RowFrag<T>& qf, float c,
-                                              float& m, float& mc, float& l, f32x16_t (&o)[2], int l31, int half) {
-  const f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31, half);
-  float tm = fmaxf(sc[0], sc[1]);
+  const float mn = fmaxf(m, tm);                            // finite from the first tile on (N >= 1)
+  const float alpha = exp_scalar<T>(m - mn, scale);         // first tile: exp(-inf) = 0
 #pragma unroll
-  for (int r = 2; r < 16; ++r) tm = fmaxf(tm, sc[r]);
-  tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-  lazy_rescale<T>(tm, c, m, mc, l, o);
-  float p[16];
-  l += exp_regs<16>(sc, p, c, mc);
-  const int lane = l31 + 32 * half;
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-  for (int g2 = 0; g2 < 2; ++g2) {
-    const bf16x8_t b = pack8<T>(p + 8 * g2);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16);
-      o[dt] = mfma16<T>(a, b, o[dt]);
-    }
-  }
+    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+  m = mn;
+  return alpha;
 }
 
 // the PARTIAL key tile: rem = N - 32 t valid keys, G = ceil(rem / 8) live register groups of four (wave-uniform branches:
-// one code path for every G -- four template instances of it spilled 35 registers around the switch)
-template <typename T, int NT>
-__device__ __forceinline__ void fwd_tile_tail(const char* ks, const char* vs, int t, int rem, const RowFrag<T>& qf, float c,
-                                              float& m, float& mc, float& l, f32x16_t (&o)[2], int l31, int half) {
-  f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31, half);      // (K rows >= N are zero in LDS: finite scores)
+// one code path for every G -- four template instances of it spilled 35 registers around a switch)
+template <typename T, int NT, bool SW = false>
+__device__ __forceinline__ void fwd_tile_tail(const char* ks, const char* vs, int t, int rem, const RowFrag<T>& qf,
+                                              float scale, float& m, float& l, f32x16_t (&o)[2], int l31, int half) {
+  f32x16_t sc = tile_times_frag<T, SW>(ks, t, qf, l31, half);  // (K rows >= N hold zeros / a copy of row N-1: finite scores)
   const int G = (rem + 7) >> 3;
   float tm = -INFINITY;
 #pragma unroll
@@ -399,8 +364,9 @@ __device__ __forceinline__ void fwd_tile_tail(const char* ks, const char* vs, in
     }
   }
   tm = fmaxf(tm, __shfl_xor(tm, 32, 64));                      // finite: offset 0 is valid and belongs to half 0
-  lazy_rescale<T>(tm, c, m, mc, l, o);
-  float p[16];
+  const float alpha = move_max<T>(tm, scale, m, o);
+  const float c = scale * LOG2E, mc = m * c;
+  float p[16], lt = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r] = 0.f;
 #pragma unroll
@@ -409,10 +375,11 @@ __device__ __forceinline__ void fwd_tile_tail(const char* ks, const char* vs, in
 #pragma unroll
       for (int j = 0; j < 4; ++j) {                            // exp2(-inf) = 0 for the masked offsets of the last group
         p[4 * g + j] = __builtin_amdgcn_exp2f(fmaf(sc[4 * g + j], c, -mc));
-        l += p[4 * g + j];
+        lt += p[4 * g + j];
       }
     }
   }
+  l = l * alpha + lt;
   const int lane = l31 + 32 * half;
 #pragma unroll
   for (int g2 = 0; g2 < 2; ++g2) {
@@ -522,7 +489,6 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
   RPO_STAMP(2);
   __syncthreads();
   RPO_STAMP(3);
-
   for (int qt = qt0 + wave; qt < qt_end; qt += 8) {
     // K/V fragments in LDS do not depend on the query tile; without this opaque copy the
     // compiler hoists all of their ds_reads out of the loop and spills them to scratch
@@ -575,13 +541,38 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
     } else
 #ifndef RPO_ATTN_OLD_LOOP           // (A/B build: the round-2..5 loop below for the 16-bit modes too)
     if constexpr (sizeof(T) == 2) {
-      // round 6 (see fwd_tile_full): lazy rescale, peeled partial key tile, key tiles past N skipped
-      const float c = scale * LOG2E;
-      float mc = 0.f;
+      // round 6 (see fwd_tile_tail): full key tiles as before, the partial one peeled, key tiles past N skipped
       const int nfull = min(N >> 5, NT), rem = N - 32 * nfull;
+      int t0 = 0;
+#ifdef RPO_ATTN_TPI2
+      // A/B build: TWO key tiles per trip -- independent score accumulators, one row maximum / exchange / rescale per 64
+      // keys: 4 dependent chains per query tile instead of 7 (not bit-identical: the maximum moves in other steps)
 #pragma unroll 1
-      for (int t = 0; t < nfull; ++t) fwd_tile_full<T, NT>(ks, vs, t, qf, c, m, mc, l, o, l31v, half);
-      if (rem > 0 && nfull < NT) fwd_tile_tail<T, NT>(ks, vs, nfull, rem, qf, c, m, mc, l, o, l31v, half);
+      for (; t0 + 1 < nfull; t0 += 2) {
+        f32x16_t sa = tile_times_frag<T>(ks, t0, qf, l31v, half);
+        f32x16_t sb = tile_times_frag<T>(ks, t0 + 1, qf, l31v, half);
+        float tm = fmaxf(sa[0], sb[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(sa[r], sb[r]));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float alpha = move_max<T>(tm, scale, m, o);
+        l = l * alpha + (exp_tile<T>(sa, m, scale) + exp_tile<T>(sb, m, scale));
+        contract_keys<T, NT>(vs, t0, sa, o, l31v, half);
+        contract_keys<T, NT>(vs, t0 + 1, sb, o, l31v, half);
+      }
+#endif
+#pragma unroll 1
+      for (int t = t0; t < nfull; ++t) {
+        f32x16_t sc = tile_times_frag<T>(ks, t, qf, l31v, half);
+        float tm = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float alpha = move_max<T>(tm, scale, m, o);
+        l = l * alpha + exp_tile<T>(sc, m, scale);
+        contract_keys<T, NT>(vs, t, sc, o, l31v, half);
+      }
+      if (rem > 0 && nfull < NT) fwd_tile_tail<T, NT>(ks, vs, nfull, rem, qf, scale, m, l, o, l31v, half);
     } else
 #endif
 #pragma unroll 1
@@ -611,6 +602,234 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const T* __restrict__ 
                         o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
     }
     RPO_STAMP(6);
+  }
+#ifdef RPO_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RPO_STAMP(7);
+}
+
+// ---- forward, 16-bit storage, round 6: the key loop STARTS while the tail of K is still in flight ------------------------
+// profiles/r06_attn_timeline.txt: of a workgroup's 16.6 k (one per CU) .. 25 k (two per CU) cycles, 4.3 .. 8.9 k pass before
+// the staging barrier -- all 384 workgroups of a launch pull their 57 KB of K / V at once, ~41 MB at the rate the fabric
+// delivers -- and the key loop (7 dependent chains of ~1.4 k cycles) cannot start before the LAST byte has landed.  Here:
+//  * K goes HBM -> LDS by DMA (global_load_lds_dwordx4: no staging registers; rows of 128 B, XOR-swizzled chunks as in
+//    gemm.hip instead of 144-B padded rows), every request of the prologue issued up front in the order q fragment, V rows,
+//    K rows [0, 128) (phase A), the rest of K (phase B);
+//  * the waves retire them with COUNTED waits: q + V -> V^T fragments on the matrix core; phase A -> barrier A -> the key
+//    loop over key tiles 0 .. 3; phase B -> barrier B -> the remaining tiles.  Left to hipcc the V loads sink into the
+//    `tile < NT` branch that uses them and every wait merges to vmcnt(0) (ISA of the first version) -- hence inline asm
+//    for the issue and the waits; the compiler issues no vector-memory instruction of its own before barrier B.
+//  * 104 VGPRs as in round 5 (a register-staged phase B: 114): two workgroups per CU AND room for the side queue's waves
+//    (same-box step time by VGPR budget of this kernel: profiles/r06_attn_variants.txt).
+// Arithmetic per query row is that of attn_fwd_kernel: bit-identical results.
+template <typename T, int NT, bool DMA> struct AL16 {
+  static constexpr int NPAD = NT * 32;
+  static constexpr int K_BYTES = NPAD * (DMA ? 128 : 144);       // DMA: swizzled, unpadded rows; else rows padded to 144 B
+  static constexpr int F_BYTES = NT * 4 * 1024;                  // V^T fragments
+  static constexpr int BYTES = K_BYTES + F_BYTES;
+  static constexpr int NDMA = (NPAD / 8 + 7) / 8;                // K requests per wave / thread (= ceil(NPAD * 8 / 512))
+};
+
+template <typename T, int NT, bool DMA>
+__global__ __launch_bounds__(512, 4) void attn_fwd16_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         const T* __restrict__ v, int64_t ld, T* out,
+                                                         int64_t ldo, int B, int H, int N, int Kp, float scale,
+                                                         int q_first) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  using L = AL16<T, NT, DMA>;
+  // K requests per thread / wave: DMA instructions of 8 rows (wave w: rows 8 (w + 8 i) ..), or 16-B register loads
+  // (thread t: chunk t + 512 i); phase A = the first PH of them = K rows [0, 128) either way
+  constexpr int NDMA = L::NDMA, PH = 2;
+  static_assert(NDMA > PH && NDMA <= 5, "the counted waits below are written out for 3 .. 5 requests");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int unit;
+  {   // block bid runs on XCD bid % 8: every XCD takes a contiguous run of (image, head) pairs, i.e. whole images
+    const int i = blockIdx.x, n = gridDim.x;
+    const int qd = n >> 3, rm = n & 7, xcd = i & 7;
+    unit = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (i >> 3);
+  }
+  const int b = unit / H, h = unit % H;
+  const T* kb = k + (int64_t)b * N * ld + h * 64;
+  const T* vb = v + (int64_t)b * N * ld + h * 64;
+  char* ks = smem;
+  char* vs = smem + L::K_BYTES;
+  const int S = N + Kp;
+  RPO_STAMP(0);
+  auto qrow = [&](int qt) -> int64_t {
+    const int sc = min(qt * 32 + l31, S - 1);
+    return sc < N ? (int64_t)b * N + sc : (int64_t)B * N + (int64_t)b * Kp + (sc - N);
+  };
+  const int qt0 = q_first >> 5, qt_end = (S + 31) >> 5;
+  const int qt_mine = qt0 + wave;
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  constexpr int NVT = (NT + 7) / 8;
+  RowFrag<T> qf;
+  u32x4 qreg[4], vreg[NVT][4], kreg[DMA ? 1 : NDMA];
+  {
+    const T* qp = q + qrow(qt_mine) * ld + h * 64 + half * 8;      // (rows are clamped: waves without a tile load a valid row)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qreg[kk]) : "v"(qp + kk * 16) : "memory");
+#pragma unroll
+    for (int ti = 0; ti < NVT; ++ti) {
+      const T* vp = vb + (int64_t)min(32 * (wave + 8 * ti) + l31, N - 1) * ld + half * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg[ti][kk]) : "v"(vp + kk * 16) : "memory");
+    }
+    // K: DMA instruction j of the workgroup = rows [8 j, 8 j + 8); wave w issues j = w, w + 8, ...; lane l -> row 8 j + (l >> 3),
+    // physical 16-B slot l & 7, which must receive logical chunk (l & 7) ^ ((row >> 1) & 7).  Rows >= N re-read row N - 1
+    // (their scores are masked or never formed); an instruction past the last one repeats the last one (same bytes).
+    if constexpr (DMA) {
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ks;
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int j = min(wave + 8 * i, L::NPAD / 8 - 1);
+        const int row = 8 * j + (lane >> 3);
+        const T* kp = kb + (int64_t)min(row, N - 1) * ld + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        const uint32_t dst = lds0 + (uint32_t)j * 1024u;           // (uniform)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(kp), "s"(dst) : "memory", "m0");
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int id = tid + i * 512;
+        const T* kp = kb + (int64_t)min(id >> 3, N - 1) * ld + (id & 7) * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg[i]) : "v"(kp) : "memory");
+      }
+    }
+  }
+  // (register path) chunk id = tid + 512 i of the [NPAD][8]-chunk K panel -> its padded LDS row; rows >= N are zeroed
+  auto commit_k = [&](int i) {
+    if constexpr (!DMA) {
+      const int id = tid + i * 512;
+      const int key = id >> 3, c = id & 7;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      if (id < L::NPAD * 8) *reinterpret_cast<u32x4*>(ks + key * 144 + c * 16) = key < N ? kreg[i] : z;
+    }
+  };
+  // q and V have landed once at most the NDMA K requests are outstanding (returns are in order)
+  if constexpr (NVT == 1)
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(qreg[0]), "+v"(qreg[1]), "+v"(qreg[2]), "+v"(qreg[3]), "+v"(vreg[0][0]),
+                 "+v"(vreg[0][1]), "+v"(vreg[0][2]), "+v"(vreg[0][3]) : "n"(NDMA) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(qreg[0]), "+v"(qreg[1]), "+v"(qreg[2]), "+v"(qreg[3]), "+v"(vreg[0][0]),
+                 "+v"(vreg[0][1]), "+v"(vreg[0][2]), "+v"(vreg[0][3]), "+v"(vreg[NVT - 1][0]), "+v"(vreg[NVT - 1][1]),
+                 "+v"(vreg[NVT - 1][2]), "+v"(vreg[NVT - 1][3]) : "n"(NDMA) : "memory");
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf.f[kk] = __builtin_bit_cast(bf16x8_t, qreg[kk]);
+  // V^T fragments: wave w transposes key tiles w, w + 8 on the matrix core (rows >= N contribute zeros)
+  {
+    const bf16x8_t i0 = ident_frag<T>(0, l31, half), i1 = ident_frag<T>(1, l31, half);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ti = 0; ti < NVT; ++ti) {
+      const int t = wave + 8 * ti;
+      if (t < NT) {
+        bf16x8_t vrows[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vrows[kk] = __builtin_bit_cast(bf16x8_t, 32 * t + l31 < N ? vreg[ti][kk] : z);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8_t fr[2];
+          transpose_tile<T>(vrows, dt, i0, i1, fr);
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2)
+            *reinterpret_cast<bf16x8_t*>(vs + (((t * 2 + dt) * 2 + g2) * 64 + lane) * 16) = fr[g2];
+        }
+      }
+    }
+  }
+  RPO_STAMP(1);
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA - PH) : "memory");   // this wave's phase-A rows are in LDS
+  } else {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(kreg[0]) : "n"(NDMA - 1) : "memory");
+    commit_k(0);
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(kreg[DMA ? 0 : 1]) : "n"(NDMA - 2) : "memory");
+    commit_k(1);
+  }
+  RPO_STAMP(2);
+  __syncthreads();                                               // barrier A: V^T of every tile, K rows [0, 128)
+  RPO_STAMP(3);
+  const int nfull = min(N >> 5, NT), rem = N - 32 * nfull;
+  const int nA = min(nfull, 2 * PH);                             // full key tiles inside phase A's rows
+  float m = -INFINITY, l = 0.f;
+  f32x16_t o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  auto tiles = [&](int ta, int tb, int l31v) {
+#pragma unroll 1
+    for (int t = ta; t < tb; ++t) {
+      f32x16_t sc = tile_times_frag<T, DMA>(ks, t, qf, l31v, half);
+      float tm = sc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float alpha = move_max<T>(tm, scale, m, o);
+      l = l * alpha + exp_tile<T>(sc, m, scale);
+      contract_keys<T, NT>(vs, t, sc, o, l31v, half);
+    }
+  };
+  auto finish = [&](int qt, int l31v) {
+    if (rem > 0 && nfull < NT) fwd_tile_tail<T, NT, DMA>(ks, vs, nfull, rem, qf, scale, m, l, o, l31v, half);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int s = qt * 32 + l31;
+    if (s < S && s >= q_first) {
+      T* orow = out + qrow(qt) * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ActIO<T>::st4(orow + 32 * dt + 8 * g + 4 * half, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv,
+                        o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+    }
+  };
+  // K / V fragments in LDS do not depend on the query tile; without this opaque copy the compiler hoists their
+  // ds_reads out of the loops and spills them
+  int l31v = l31;
+  asm volatile("" : "+v"(l31v));
+  const bool have = qt_mine < qt_end;                            // (wave-uniform)
+  if (have) tiles(0, nA, l31v);
+  RPO_STAMP(4);
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's phase-B rows are in LDS
+  } else {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(kreg[DMA ? 0 : 2]) : "n"(NDMA - 3) : "memory");
+    commit_k(2);
+    if constexpr (NDMA > 3) {
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(kreg[DMA ? 0 : (NDMA > 3 ? 3 : 0)]) : "n"(NDMA > 3 ? NDMA - 4 : 0) : "memory");
+      commit_k(3);
+    }
+    if constexpr (NDMA > 4) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[DMA ? 0 : NDMA - 1]) : : "memory");
+      commit_k(NDMA - 1);
+    }
+  }
+  __syncthreads();                                               // barrier B: the rest of K
+  RPO_STAMP(5);
+  if (have) {
+    tiles(nA, nfull, l31v);
+    finish(qt_mine, l31v);
+  }
+  RPO_STAMP(6);
+  for (int qt = qt_mine + 8; qt < qt_end; qt += 8) {             // (S > 256: ViT-L/14's ninth query tile)
+    asm volatile("" : "+v"(l31v));
+    qf.load(q + qrow(qt) * ld + h * 64, half);
+    m = -INFINITY; l = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    tiles(0, nfull, l31v);
+    finish(qt, l31v);
   }
 #ifdef RPO_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1134,6 +1353,22 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
                int N, int Kp, float scale, int q_first, hipStream_t s) {
 #ifdef RPO_ATTN_FWD_V2            // (A/B build: every score tile in registers, one workgroup per CU -- attn_fwd2_kernel)
   if constexpr (sizeof(T) == 2) return launch_fwd2<T, NT>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
+#endif
+#if !defined(RPO_ATTN_OLD_LOOP) && !defined(RPO_ATTN_ONE_BARRIER) && !defined(RPO_ATTN_SPLIT) && !defined(RPO_ATTN_FWD_2PASS)
+  if constexpr (sizeof(T) == 2) {       // round 6: two-phase staging (A/B build -DRPO_ATTN_ONE_BARRIER: the one-barrier kernel)
+    static rpo_lds_mask_t lds16_ok{0};
+#ifdef RPO_ATTN_DMA                 // (A/B build: K by LDS-DMA into swizzled rows; default: 16-B register loads, padded rows)
+    constexpr bool kdma = true;
+#else
+    constexpr bool kdma = false;
+#endif
+    auto k16 = attn_fwd16_kernel<T, NT, kdma>;
+    constexpr int bytes16 = AL16<T, NT, kdma>::BYTES;
+    if (int rc = rpo_allow_lds(reinterpret_cast<const void*>(k16), bytes16, &lds16_ok)) return rc;
+    hipLaunchKernelGGL(k16, dim3(B * H), dim3(512), bytes16, s, static_cast<const T*>(q), static_cast<const T*>(k),
+                       static_cast<const T*>(v), ld, static_cast<T*>(out), ldo, B, H, N, Kp, scale, q_first);
+    return rpo_launch_status();
+  }
 #endif
   static rpo_lds_mask_t lds_ok{0};
 #ifdef RPO_ATTN_FWD_2PASS         // (A/B build: two-pass softmax with recomputed scores, two workgroups per CU)

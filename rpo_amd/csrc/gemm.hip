@@ -1034,7 +1034,7 @@ int dispatch_f32out(int epi, const GemmParams& p, hipStream_t s) {
 
 #ifdef RPO_TIMELINE
 __device__ unsigned long long* g_timeline = nullptr;
-extern "C" int rpo_debug_set_timeline(unsigned long long* buf) {
+extern "C" __attribute__((visibility("default"))) int rpo_debug_set_timeline(unsigned long long* buf) {   // (debug build only: not in the header)
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf));
 }
 #endif

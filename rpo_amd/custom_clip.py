@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import synth
 from .config import RPOConfig
-from .engine import Engine
+from .engine import Engine, make_engine
 
 
 class PromptLearner(nn.Module):
@@ -104,7 +104,7 @@ class CustomCLIP(nn.Module):
                 raise ValueError("tokens [n_cls, context] are required for any class set other than the bundled "
                                  "Oxford-Pets base split (synthetic ids are for tests and bench only)")
             tokens = synth.oxford_pets_base_tokens()
-        self.engine = Engine(cfg, state_dict, tokens, device, act_dtype, max_batch)
+        self.engine = make_engine(cfg, state_dict, tokens, device, act_dtype, max_batch)
         self.prompt_learner = PromptLearner(self.engine)
         # trainers/rpo.py:63-67,77-81: drawn from torch's seeded global generator unless injected
         tp, ip = prompts if prompts is not None else init_prompts(state_dict, cfg.K, cfg.d_t, cfg.d_v)

@@ -138,6 +138,23 @@ class GradSync:
         b = dist.get_backend()
         return f"{'rccl' if b == 'nccl' else b} all-reduce of the flat prompt-gradient buffer, {dist.get_world_size()} ranks"
 
+    def comm_world_size(self) -> int:
+        """The world size the COMMUNICATOR reports (not the environment's): 1 for a lone process without a group."""
+        return dist.get_world_size() if (self.enabled and dist.is_initialized()) else 1
+
+    def rank_devices(self, device) -> list:
+        """`rank r: <device name> (cuda:i, pci bus)` for every rank of the communicator, gathered through it."""
+        try:
+            p = torch.cuda.get_device_properties(device)
+            mine = f"rank {self.rank}: {p.name} ({device}, pci {getattr(p, 'pci_bus_id', -1):02x})"
+        except Exception:                            # noqa: BLE001 -- CPU-only test runs
+            mine = f"rank {self.rank}: {device}"
+        if not (self.enabled and dist.is_initialized()):
+            return [mine]
+        box = [None] * dist.get_world_size()
+        dist.all_gather_object(box, mine)
+        return box
+
     def shard(self, global_batch: int) -> Tuple[int, int]:
         """(first image, count) of this rank's contiguous shard; shards must be equal so that
         the mean of shard means is the global mean."""

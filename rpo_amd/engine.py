@@ -31,6 +31,7 @@ import os
 from ._lib import (EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_RESID, EPI_LN_BIAS, EPI_LN_BIAS_QGELU, EPI_NONE, EPI_PATCH,
                    EPI_QGELU_BWD)
 from .config import RPOConfig
+from .engine_coop import CoopEngineMixin
 
 import contextlib
 
@@ -38,12 +39,6 @@ SCALE = 1.0 / math.sqrt(64.0)
 _NO_PROBE = contextlib.nullcontext()
 
 
-def _xenv(name: str, default: str = "0") -> str:
-    """Switch of a measured-slower EXPERIMENT: read only when RPO_EXPERIMENTAL=1 -- which also
-    selects the -DRPO_EXPERIMENTAL build of the library (rpo_amd/_lib.py) -- otherwise the default.  The default train
-    step, the eval path and the sibling trainers never take these branches."""
-    from ._lib import EXPERIMENTAL
-    return os.environ.get(name, default) if EXPERIMENTAL else default
 # split-K factors of the two fp32-output dX GEMMs of a block's backward (few output tiles, long K):
 # d c_fc has K = 4d, d q-proj has K = d.  Slabs are summed in fixed order by rpo_layernorm_bwd.  Tuned at step level:
 # 4, 6, 8 slabs for c_fc and 3, 4 for the q-projection were slower (more slabs cost output bandwidth).
@@ -72,7 +67,11 @@ class _Block:
     w_fc_ln: Optional[torch.Tensor] = None; s_fc: Optional[torch.Tensor] = None; b_fc_ln: Optional[torch.Tensor] = None
 
 
-class Engine:
+class Engine(CoopEngineMixin):
+    """The product engine: the RPO step, its eval branch, plain CLIP, and (engine_coop.CoopEngineMixin) the sibling
+    trainers.  The measured-slower experiments of rounds 3 / 4 are NOT here: rpo_amd/experimental.py subclasses this class
+    and overrides the hooks marked "experiment hook" below; `make_engine` returns that subclass only under
+    RPO_EXPERIMENTAL=1, so a default run imports and executes none of it."""
     def __init__(self, cfg: RPOConfig, state_dict: Dict[str, np.ndarray], tokens: np.ndarray,
                  device: torch.device, act_dtype: torch.dtype = torch.bfloat16, max_batch: int = 32):
         if not torch.cuda.is_available():
@@ -294,7 +293,6 @@ class Engine:
         # must run with RPO_NO_HILO=1 (tools/probe_alias_buffers.py does).
         self.x = [f32(R, dv) for _ in range(Lv + 1)]
         self.xm = [f32(R, dv) for _ in range(Lv)]
-        self.mlp_counters = torch.zeros(B + 1, dtype=torch.int32, device=dev)   # rpo_mlp_fused (experiment): one per row unit + give-ups, never reset
         self.h = a(R, dv)
         self.h_lo = a(R, dv)                         # lo half of the residual stream (hi / lo mode: _image_forward)
         self.ln_stats = f32(R, dv // 64, 2)          # per-row partial LayerNorm statistics of the tensor self.h copies
@@ -311,13 +309,6 @@ class Engine:
         self.d_img_f = f32(Rp, e)
         self.d_img_f_a = a(Rp, e)
         self.dy_v = f32(max(SPLIT_FC, SPLIT_Q, 4), Rp, dv)       # (rpo_gemm_ws splits d c_fc in up to four)
-        # the persistent backward chain (rpo_chain_bwd): 4 k-slice slabs, its scratch (one per tower: the two chains run
-        # concurrently), optional stage timeline (tools/chain_timeline.py sets it)
-        from ._lib import EXPERIMENTAL
-        self.dy4_v = f32(4, Rp, dv) if EXPERIMENTAL else None
-        self.chain_state_v = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev) if EXPERIMENTAL else None
-        self.chain_state_t = torch.zeros(ops.chain_state() // 4, dtype=torch.int32, device=dev) if EXPERIMENTAL else None
-        self.chain_timeline = None
         self.dxa_v, self.dxb_v = f32(Rp, dv), f32(Rp, dv)
         self.dxc_v = a(Rp, dv)
         self.du_v = a(Rp, 4 * dv)
@@ -338,7 +329,6 @@ class Engine:
         self.d_text_f_a = a(Rt, e)
         self.ln_stats_t = f32(Rt, dt // 64, 2)
         self.dy_t = f32(max(SPLIT_FC, SPLIT_Q, 4), Rt, dt)
-        self.dy4_t = f32(4, Rt, dt) if EXPERIMENTAL else None
         self.dxa_t, self.dxb_t = f32(Rt, dt), f32(Rt, dt)
         self.dxc_t = a(Rt, dt)
         self.du_t = a(Rt, 4 * dt)
@@ -477,13 +467,10 @@ class Engine:
         # whose row statistics are over 96 columns instead of 64 (rpo_gemm_args.ln_group): grp says which.
         units = (N, K, Rf)
         which = os.environ.get("RPO_RESID_UNITS", "all")            # A/B switch: all | c_proj | none
-        # SPLIT mode (round 4): when an image's N + K rows do not fit a one-round tile but its N frozen rows do (ViT-B/16
-        # at K = 48: 245 > 224 rows), the frozen rows keep the one-round kernels -- row units of N + 0 rows, rows [0, Rf) --
-        # and the B*K prompt rows take their own launches on the generic tiles, as the last block's always do.  Rows never
-        # mix inside a GEMM, so results are those of the whole-stream launches up to the tile shapes' summation order.
-        # OPT-IN (RPO_SPLIT=1): measured 3 % SLOWER at K = 48, B = 32 (4.287 vs 4.154 ms, two alternating pairs,
-        # profiles/r04_ab_split_k48.txt) -- the four extra 1536-row launches per block (~10 us each) cost more than the
-        # one-round kernels save on the frozen rows.
+        # SPLIT mode (experiment hook, rpo_amd/experimental.py: RPO_SPLIT): the frozen rows on the one-round kernels -- row
+        # units of N + 0 rows, rows [0, Rf) -- and the B*K prompt rows on their own launches, as the last block's always are.
+        # Rows never mix inside a GEMM, so results are those of the whole-stream launches up to the tile shapes' summation
+        # order.  Measured 3 % SLOWER at K = 48 (profiles/r04_ab_split_k48.txt); never taken by this class (_split_rows).
         split = self._split_rows(B)
         # small batches: every "wide" launch is a small-M GEMM and goes to rpo_gemm_ws (no row units, 64-column statistics)
         # (measured, tools/ab_env.py --extra "--batch B": B = 4 step 1.509 vs 1.554 ms, B = 8 1.958 vs 1.723 ms -- from
@@ -546,8 +533,6 @@ class Engine:
             return {"out": b.w_out, "proj": b.w_proj, "fc": b.w_fc_ln if fold else b.w_fc,
                     "in": b.w_in_ln if (fold and b is not self.vis[0]) else b.w_in}[what]
         no_probe = lambda name: _NO_PROBE
-        mlp_fused = _xenv("RPO_MLP_FUSED", "0")
-        mlp_fused = mlp_fused if mlp_fused in ("1", "safe") and self.act != torch.float32 else ""
         for l, blk in enumerate(self.vis):
             x, xm, xo, qkv = self.x[l][:R], self.xm[l][:R], self.x[l + 1][:R], self.qkv[l][:R]
             # ln_1 + in-proj.  Folded (l > 0): h already holds the 16-bit copy of x[l] and st its row statistics, both
@@ -619,14 +604,14 @@ class Engine:
                                **res_p, **prod_p, prefetch=pf_of("proj", l) if wide else None)
                 if not wide or small:         # (64-column statistics either way; no row units)
                     proj_kw.pop("row_units"); proj_kw.pop("ln_group", None)
-                # EXPERIMENT (round 4, RPO_MLP_FUSED=1 / =safe): c_fc -> c_proj of a whole-batch block as ONE launch
-                # (rpo_mlp_fused: the 8 workgroups of an image hand g over through their XCD's L2 at a counter)
-                if fold and wide and mlp_fused:
+                # experiment hook (rpo_amd/experimental.py: RPO_MLP_FUSED): c_fc -> c_proj of a whole-batch block as ONE
+                # launch; None in this class
+                if fold and wide and self._fused_mlp is not None:
                     fc_kw = dict(a=h[lo:hi], w=blk.w_fc_ln, out=g[lo:hi], epilogue=EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                                  aux=aux, aux_row0=aux_row0, ln_stats=so[lo:hi], ln_colsum=blk.s_fc, row_units=un,
                                  ln_group=go, prefetch=pf_of("fc", l))
                     with timed("c_fc"):
-                        done = ops.mlp_fused(fc_kw, proj_kw, self.mlp_counters, safe=(mlp_fused == "safe"))
+                        done = self._fused_mlp(fc_kw, proj_kw)
                     if done:
                         continue
                 if fold:
@@ -650,23 +635,20 @@ class Engine:
         ops.layernorm_fwd(self.x[-1][Rf:R], self.ln_post[0], self.ln_post[1], self.y_post[:Rp])   # rpo.py:210
         self._gemm(self.y_post[:Rp], self.img_proj_t, self.img_f[:Rp], EPI_NONE)
 
+    # ------------------------------------------------------------------ experiment hooks (overridden in experimental.py)
+    _fused_mlp = None                               # callable(fc_kw, proj_kw) -> bool: c_fc -> c_proj as one launch
+
     def _split_rows(self, B: int) -> bool:
-        """Whether the image forward runs its frozen rows and its prompt rows as separate launches (see _image_forward):
-        16-bit modes with the LayerNorm fold, when the one-round row-unit kernels take an image's N frozen rows but not
-        its N + K rows (RPO_SPLIT=1), or wherever they take the frozen rows (RPO_SPLIT=force: the test's switch)."""
-        cfg = self.cfg
-        mode = _xenv("RPO_SPLIT", "0")          # "1": where the whole rows do not fit; "force": wherever the frozen rows do
-        if self.act == torch.float32 or not self.fold_ln or mode not in ("1", "force") or cfg.K == 0:
-            return False
-        key = ("split", B)
-        if key not in self._stats_group:
-            N, K, dv = cfg.n_frozen, cfg.K, cfg.d_v
-            Rf, R = B * N, B * (N + K)
-            whole = ops.gemm_hilo_ok(R, dv, dv, self.act, (N, K, Rf), ops.gemm_stats_group(R, dv, dv, self.act, (N, K, Rf)))
-            frozen = ops.gemm_hilo_ok(Rf, dv, dv, self.act, (N, 0, Rf), ops.gemm_stats_group(Rf, dv, dv, self.act, (N, 0, Rf)))
-            # (round 4: with the 256x96 geometry K = 48 -- 245 rows -- fits whole; "1" now engages from 257 rows on)
-            self._stats_group[key] = bool(frozen and (mode == "force" or not whole))
-        return self._stats_group[key]
+        """Frozen rows and prompt rows of the image forward as separate launches?  Never, in the product engine."""
+        return False
+
+    def joint_backward_ok(self, B: Optional[int] = None) -> bool:
+        """Both backward chains as one chain of paired launches?  Never, in the product engine."""
+        return False
+
+    def _bwd_fold_limits(self) -> tuple:
+        """(largest K, widths) for which the attention backward folds the d out-proj GEMM in."""
+        return 64, (512, 768, 1024)
 
     # ------------------------------------------------------------------ backward pieces
     def _rows_backward(self, blocks: List[_Block], x: List[torch.Tensor], xm: List[torch.Tensor],
@@ -687,6 +669,10 @@ class Engine:
         #  and read the row-major d x d operands)
         ws = self.use_ws and dxa.shape[0] < 2048
         s_fc, s_q = (SPLIT_FC, SPLIT_Q) if not ws else (2, 1)
+        if dxa.shape[0] >= 2048:
+            # a chain of thousands of rows (the text tower from 86 classes on at K = 24: 24 000 rows at ImageNet's 1000) has
+            # hundreds of output tiles by itself: split-K would only write and re-read fp32 slabs (49 MB each at 24 000 rows)
+            s_fc = s_q = 1
         if ws and "RPO_WS_SPLITS" in os.environ:             # A/B: "FCxQ" (step-level tuning, tools/ab_env.py)
             s_fc, s_q = (int(v) for v in os.environ["RPO_WS_SPLITS"].split("x"))
         for l in reversed(range(len(blocks))):
@@ -742,142 +728,37 @@ class Engine:
                           None if self.act == torch.float32 else dxc)
 
         # 16-bit modes, K <= 64, d = 512 / 768 / 1024: the d out-proj GEMM runs inside the attention backward kernel
-        # (round 4: d = 1024 -- ViT-L/14 -- and K in (32, 64] -- one workgroup per 32-query tile; A/B: RPO_BWD_FOLD_R3=1
-        # restores the round-3 coverage)
-        r3 = _xenv("RPO_BWD_FOLD_R3") == "1"
-        fold_out = (self.act != torch.float32 and K <= (32 if r3 else 64) and dv in ((512, 768) if r3 else (512, 768, 1024))
-                    and os.environ.get("RPO_NO_BWD_FOLD") != "1")
+        # (round 4: d = 1024 -- ViT-L/14 -- and K in (32, 64] -- one workgroup per 32-query tile)
+        kmax, widths = self._bwd_fold_limits()
+        fold_out = (self.act != torch.float32 and K <= kmax and dv in widths and os.environ.get("RPO_NO_BWD_FOLD") != "1")
 
         def attn_bwd(l, da, dq):
             qkv = self.qkv[l]
             if fold_out:
-                ops.attn_readonly_bwd_proj(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da,
-                                           self.vis[l].w_out_t, dq, nb, H, N, K, SCALE)
+                with self._timed("attn_bwd_proj"):
+                    ops.attn_readonly_bwd_proj(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da,
+                                               self.vis[l].w_out_t, dq, nb, H, N, K, SCALE)
             else:
                 ops.attn_readonly_bwd(qkv[Rf + r0:Rf + r1, :dv], qkv[f0:f1, dv:2 * dv], qkv[f0:f1, 2 * dv:], da, dq,
                                       nb, H, N, K, SCALE)
 
-        if nb == B and self.chain_ok("v", nb):      # (never for a part of the batch: one scratch buffer, one resident chain per tower)
-            # the 6 x layers stages as ONE persistent launch (rpo_chain_bwd, csrc/chain.hip): A/B switch RPO_CHAIN=0
-            layers = [dict(w_proj_t=b.w_proj_t, w_fc_t=b.w_fc_t, w_out_t=b.w_out_t, w_q_t=b.w_q_t, aux=self.u[l][r0:r1],
-                           x_ln2=self.xm[l][Rf + r0:Rf + r1], x_ln1=self.x[l][Rf + r0:Rf + r1], ln2_w=b.ln2_w, ln1_w=b.ln1_w,
-                           q_rows=self.qkv[l][Rf + r0:Rf + r1, :dv], k=self.qkv[l][f0:f1, dv:2 * dv],
-                           v=self.qkv[l][f0:f1, 2 * dv:]) for l, b in enumerate(self.vis)]
-            ops.chain_bwd(layers, units=nb, Kp=K, d=dv, H=H, keys=N, dtype=self.act, ldx=dv, ldq=3 * dv, ldkv=3 * dv,
-                          dxa=dxa, dxb=dxb, dxc=dxc, du=self.du_v[r0:r1], dq=self.dq_v[r0:r1], dy=self.dy4_v[:, r0:r1],
-                          scale=SCALE, state=self.chain_state_v, timeline=self.chain_timeline)
-            dx = dxa
-        else:
-            dx = self._rows_backward(self.vis, [t[Rf + r0:Rf + r1] for t in self.x[:-1]], [t[Rf + r0:Rf + r1] for t in self.xm],
-                                     [t[r0:r1] for t in self.u], dxa, dxb, dxc, self.du_v[r0:r1], self.da_v[r0:r1],
-                                     self.dq_v[r0:r1], self.dy_v[:, r0:r1], attn_bwd, fold_out=fold_out)
+        dx = self._image_chain(B, b0, b1, attn_bwd, fold_out)
         # through ln_pre (rpo.py:206) to the appended prompt rows
         ops.layernorm_bwd(dx, self.x_pre[Rf + r0:Rf + r1], self.ln_pre[0], None, dxb)
 
-    def chain_ok(self, tower: str, units: int) -> bool:
-        """Whether the prompt-row backward chain of a tower ("v" / "t") runs as one persistent launch (rpo_chain_bwd):
-        16-bit modes with the QuickGELU derivative saved in the act dtype, widths / key counts / rows per group the
-        kernel covers.  OPT-IN (RPO_CHAIN=1; the text tower also needs RPO_CHAIN_TEXT=1): measured SLOWER than the
-        launch-per-stage chain -- image tower at B = 32: 1.10-1.20 ms against 0.77 ms (profiles/r04_chain_*.txt).  A
-        stage costs ~5-6 us of drain + counter + poll + first dependent load whether or not a kernel boundary sits in
-        it, and one workgroup per CU cannot keep enough LDS-DMA bytes in flight (72 KB ring: ~40 GB/s per CU)."""
-        if self.act == torch.float32 or _xenv("RPO_CHAIN") != "1" or os.environ.get("RPO_AUX_F32") == "1":
-            return False
-        cfg = self.cfg
-        if tower == "v":
-            if _xenv("RPO_CHAIN_IMAGE", "1") == "0":     # (text tower alone: RPO_CHAIN=1 RPO_CHAIN_TEXT=1 RPO_CHAIN_IMAGE=0)
-                return False
-            return ops.chain_bwd_ok(cfg.layers_v, units, cfg.K, cfg.d_v, cfg.heads_v, cfg.n_frozen, self.act)
-        if _xenv("RPO_CHAIN_TEXT", "0") != "1" or self.Lmax > 96:
-            return False
-        return ops.chain_bwd_ok(cfg.layers_t, units, cfg.K, cfg.d_t, cfg.heads_t, self.Lmax, self.act)
+    def _image_chain(self, B: int, b0: int, b1: int, attn_bwd, fold_out: bool) -> torch.Tensor:
+        """The 6 x layers stages of the image tower's prompt-row chain for images [b0, b1), one launch per stage
+        (experiment hook: rpo_amd/experimental.py runs them as ONE persistent launch under RPO_CHAIN=1)."""
+        K, Rf = self.cfg.K, B * self.cfg.n_frozen
+        r0, r1 = b0 * K, b1 * K
+        return self._rows_backward(self.vis, [t[Rf + r0:Rf + r1] for t in self.x[:-1]], [t[Rf + r0:Rf + r1] for t in self.xm],
+                                   [t[r0:r1] for t in self.u], self.dxa_v[r0:r1], self.dxb_v[r0:r1], self.dxc_v[r0:r1],
+                                   self.du_v[r0:r1], self.da_v[r0:r1], self.dq_v[r0:r1], self.dy_v[:, r0:r1], attn_bwd,
+                                   fold_out=fold_out)
 
     def _image_backward_finish(self, B: int) -> None:
         """sum over the batch (.repeat, rpo.py:204)"""
         ops.reduce_groups(self.dxb_v[:B * self.cfg.K], self.g_img, B)
-
-    # ------------------------------------------------------------------ both backward chains as ONE chain of launches
-    def joint_backward_ok(self, B: Optional[int] = None) -> bool:
-        """The two prompt-row chains can be issued pairwise (one launch per stage for both towers) when both attention
-        backwards run with the d out-proj GEMM folded in: 16-bit modes, K <= 32, widths 512 / 768, <= 96 text keys.
-        Measured and NOT the default: the 64x64-tile GEMMs of the chains are bound by the CUs' LDS-DMA rate, not by
-        latency (a 64-deep k-tile of a 64x64 tile is 16 KB at the ~34 B/clk a CU's DMA path delivers = the ~480 cycles
-        per k-tile of the timeline), so a paired launch takes the SUM of its two problems' times (d c_proj pair 23.3 us
-        against 15 + 9 alone, attention pair 21.9 against 17.3 + 8.9), and what is left to gain is the second queue.
-        Same box, backward phase alone at B = 4 / 8 / 16 / 32: 0.70 / 0.71 / 0.78 / 1.02 ms paired against 0.73 / 0.73 /
-        0.78 / 0.91 ms as two chains on two streams; whole step 1.70 / 2.04 / - / 3.20 ms against 1.65 / 1.97 / - / 3.02.
-        RPO_JOINT_BWD=1 turns it on (results are bit-identical either way: tests/test_gpu_model.py)."""
-        cfg = self.cfg
-        can = (self.act != torch.float32 and cfg.K <= 32 and cfg.d_v == 768 and cfg.d_t in (512, 768)
-               and self.Lmax <= 96 and cfg.n_frozen > 96 and cfg.n_frozen <= 224
-               and os.environ.get("RPO_NO_BWD_FOLD") != "1")
-        return can and _xenv("RPO_JOINT_BWD") == "1"
-
-    def _joint_backward(self, B: int) -> None:
-        """_image_backward + _text_backward with every stage of the two chains in ONE launch (rpo_gemm_nt_pair,
-        rpo_layernorm_bwd_pair, rpo_attn_bwd_proj_pair): the chains have the same six stages per block, and as two
-        chains on two queues their ~150 small kernels delayed each other (backward pair 0.93 ms against 0.78 ms for the
-        image chain alone, profiles/README.md).  The arithmetic of every problem is that of the separate launches."""
-        cfg = self.cfg
-        N, K, dv, dt = cfg.n_frozen, cfg.K, cfg.d_v, cfg.d_t
-        Rf, Rp, Rt, n = B * N, B * K, self.Rt, cfg.n_cls
-        R = Rf + Rp
-        pf = self._pf_chains
-        V = dict(blocks=self.vis, x=[t[Rf:R] for t in self.x], xm=[t[Rf:R] for t in self.xm], u=[t[:Rp] for t in self.u],
-                 dxa=self.dxa_v[:Rp], dxb=self.dxb_v[:Rp], dxc=self.dxc_v[:Rp], du=self.du_v[:Rp], dq=self.dq_v[:Rp],
-                 dy=self.dy_v[:, :Rp])
-        T = dict(blocks=self.txt, x=self.xt, xm=self.xtm, u=self.ut, dxa=self.dxa_t, dxb=self.dxb_t, dxc=self.dxc_t,
-                 du=self.du_t, dq=self.dq_t, dy=self.dy_t)
-
-        def attn_args(c, l):
-            if c is V:
-                qkv = self.qkv[l]
-                return dict(q_rows=qkv[Rf:R, :dv], k=qkv[:Rf, dv:2 * dv], v=qkv[:Rf, 2 * dv:], dx=c["dxc"],
-                            w_out_t=self.vis[l].w_out_t, dq=c["dq"], groups=B, H=cfg.heads_v, keys=N, Kp=K, scale=SCALE)
-            kv = self.kv_t[l]
-            return dict(q_rows=self.qt[l], k=kv[:, :dt], v=kv[:, dt:], dx=c["dxc"], w_out_t=self.txt[l].w_out_t,
-                        dq=c["dq"], groups=n, H=cfg.heads_t, keys=self.Lmax, Kp=K, scale=SCALE, key_len=self.len_i32,
-                        key_stride=self.Lmax)
-
-        def gemm(calls):
-            if len(calls) == 2:
-                ops.gemm_nt_pair(*calls)
-            else:
-                ops.gemm_nt(**calls[0])
-
-        def ln(calls):
-            if len(calls) == 2:
-                ops.layernorm_bwd_pair(*calls)
-            else:
-                ops.layernorm_bwd(**calls[0])
-
-        # heads of the chains: d projection, then ln_post / ln_final (rpo.py:210 / :183)
-        gemm([dict(a=self.d_img_f_a[:Rp], w=self.img_proj, out=self.dy_v[0, :Rp], epilogue=EPI_NONE,
-                   prefetch=self.vis[-1].w_proj_t if pf else None),
-              dict(a=self.d_text_f_a, w=self.text_proj, out=self.dy_t[0], epilogue=EPI_NONE,
-                   prefetch=self.txt[-1].w_proj_t if pf else None)])
-        ln([dict(dy=self.dy_v[0, :Rp], x=V["x"][-1], gamma=self.ln_post[0], dres=None, dx=V["dxa"], dx_cast=V["dxc"]),
-            dict(dy=self.dy_t[0], x=self.xt[-1], gamma=self.ln_final[0], dres=None, dx=T["dxa"], dx_cast=T["dxc"])])
-        Lv, Lt = len(self.vis), len(self.txt)
-        for s_ in range(max(Lv, Lt)):
-            live = [(c, len(c["blocks"]) - 1 - s_) for c in (V, T) if len(c["blocks"]) - 1 - s_ >= 0]
-            blk = lambda c, l: c["blocks"][l]
-            # the six stages of _rows_backward, for every tower that still has a block at this depth
-            gemm([dict(a=c["dxc"], w=blk(c, l).w_proj_t, out=c["du"], epilogue=EPI_QGELU_BWD, aux=c["u"][l],
-                       prefetch=blk(c, l).w_fc_t if pf else None) for c, l in live])                       # d c_proj, d QuickGELU
-            gemm([dict(a=c["du"], w=blk(c, l).w_fc_t, out=c["dy"][:SPLIT_FC], epilogue=EPI_NONE, split_k=SPLIT_FC,
-                       prefetch=blk(c, l).w_oq_t if pf else None) for c, l in live])                       # d c_fc
-            ln([dict(dy=c["dy"][:SPLIT_FC], x=c["xm"][l], gamma=blk(c, l).ln2_w, dres=c["dxa"], dx=c["dxb"],
-                     dx_cast=c["dxc"]) for c, l in live])
-            ops.attn_bwd_proj_pair(*[attn_args(c, l) for c, l in live])                                    # d out-proj + attention
-            gemm([dict(a=c["dq"], w=blk(c, l).w_q_t, out=c["dy"][:SPLIT_Q], epilogue=EPI_NONE, split_k=SPLIT_Q,
-                       prefetch=c["blocks"][l - 1].w_proj_t if (pf and l > 0) else None) for c, l in live])  # d q-projection
-            ln([dict(dy=c["dy"][:SPLIT_Q], x=c["x"][l], gamma=blk(c, l).ln1_w, dres=c["dxb"], dx=c["dxa"],
-                     dx_cast=c["dxc"]) for c, l in live])
-        # image: through ln_pre (rpo.py:206) to the appended prompt rows; both: sum over the batch / the classes (.repeat)
-        ops.layernorm_bwd(V["dxa"], self.x_pre[Rf:R], self.ln_pre[0], None, V["dxb"])
-        ops.reduce_groups(V["dxb"], self.g_img, B)
-        ops.reduce_groups(T["dxa"], self.g_text, n)
 
     def _text_backward(self) -> None:
         self._ws_cfg = self._ws_text_cfg_bwd
@@ -896,37 +777,22 @@ class Engine:
         ops.layernorm_bwd(self.dy_t[0], self.xt[-1], self.ln_final[0], None, dxa,
                           None if self.act == torch.float32 else dxc)
 
-        # RPO_TEXT_BWD_FOLD=1 (16-bit modes, K <= 32, <= 96 keys): the MFMA attention backward of the image tower with
-        # per-class key counts and the d out-proj GEMM folded in (rpo_attn_bwd_proj_pair) instead of a GEMM + the VALU
-        # kernel.  Measured and NOT the default: the text chain alone gets 16 % shorter (583 -> 490 us) and the step 0.4 %
-        # LONGER (3.016 vs 3.003 ms at B = 32, three alternating pairs; 0 at B = 4) -- the text chain is not what the step
-        # waits for, its kernels' footprint on the CUs is, and the MFMA kernel (250 VGPRs, 66 KB of LDS per workgroup)
-        # stands in the image chain's way more than the VALU kernel + a 64x64 GEMM do.
-        fold_out = (self.act != torch.float32 and K <= 32 and dt in (512, 768) and self.Lmax <= 96
-                    and os.environ.get("RPO_NO_BWD_FOLD") != "1" and _xenv("RPO_TEXT_BWD_FOLD") == "1")
+        dx = self._text_chain()
+        ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
+
+    def _text_chain(self) -> torch.Tensor:
+        """The 6 x layers stages of the text tower's prompt-row chain, one launch per stage (experiment hooks in
+        rpo_amd/experimental.py: RPO_CHAIN_TEXT -- one persistent launch; RPO_TEXT_BWD_FOLD -- the MFMA attention backward
+        with the d out-proj GEMM folded in)."""
+        cfg = self.cfg
+        n, K, dt, H = cfg.n_cls, cfg.K, cfg.d_t, cfg.heads_t
 
         def attn_bwd(l, da, dq):
             kv = self.kv_t[l]
-            if fold_out:
-                ops.attn_bwd_proj_pair(dict(q_rows=self.qt[l], k=kv[:, :dt], v=kv[:, dt:], dx=da,
-                                            w_out_t=self.txt[l].w_out_t, dq=dq, groups=n, H=H, keys=self.Lmax, Kp=K,
-                                            scale=SCALE, key_len=self.len_i32, key_stride=self.Lmax))
-            else:
-                ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
+            ops.text_attn_bwd(self.qt[l], kv[:, :dt], kv[:, dt:], da, dq, self.len_i32, n, K, self.Lmax, H, SCALE)
 
-        if self.chain_ok("t", n):
-            # opt-in (RPO_CHAIN=1 RPO_CHAIN_TEXT=1): the text tower's chain as one persistent launch, classes as units
-            layers = [dict(w_proj_t=b.w_proj_t, w_fc_t=b.w_fc_t, w_out_t=b.w_out_t, w_q_t=b.w_q_t, aux=self.ut[l],
-                           x_ln2=self.xtm[l], x_ln1=self.xt[l], ln2_w=b.ln2_w, ln1_w=b.ln1_w, q_rows=self.qt[l],
-                           k=self.kv_t[l][:, :dt], v=self.kv_t[l][:, dt:]) for l, b in enumerate(self.txt)]
-            ops.chain_bwd(layers, units=n, Kp=K, d=dt, H=H, keys=self.Lmax, dtype=self.act, key_len=self.len_i32,
-                          key_stride=self.Lmax, ldx=dt, ldq=dt, ldkv=2 * dt, dxa=dxa, dxb=dxb, dxc=dxc, du=self.du_t,
-                          dq=self.dq_t, dy=self.dy4_t, scale=SCALE, state=self.chain_state_t)
-            dx = dxa
-        else:
-            dx = self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, dxa, dxb, dxc, self.du_t, self.da_t,
-                                     self.dq_t, self.dy_t, attn_bwd, fold_out=fold_out, tt=self._text_tiles)
-        ops.reduce_groups(dx, self.g_text, n)            # same prompt row written into every class
+        return self._rows_backward(self.txt, self.xt[:-1], self.xtm, self.ut, self.dxa_t, self.dxb_t, self.dxc_t, self.du_t,
+                                   self.da_t, self.dq_t, self.dy_t, attn_bwd, fold_out=False, tt=self._text_tiles)
 
     # ------------------------------------------------------------------ public
     def forward_eval(self, image: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
@@ -1017,258 +883,6 @@ class Engine:
                          self.logits[:B], None, None, None, self.head_ws)
         return self.logits[:B]
 
-    # ------------------------------------------------------------------ CoOp / CoCoOp: training context vectors
-    def coop_layout(self, n_ctx: int, class_token_position: str = "end"):
-        """Where CoOp's PromptLearner.forward (trainers/coop.py:117-183) puts things: for every class c and sequence
-        position p, `src[c, p]` = the position of the "X X .. name." prompt whose TOKEN embedding sits there (-1 where a
-        context vector sits) and `ctx_pos[c, j]` = the position of context vector j.  "end": [SOS | ctx | name . EOT];
-        "middle": [SOS | ctx[:n/2] | name | ctx[n/2:] | . EOT]; "front": [SOS | name | ctx | . EOT].  name_len of a class
-        = its prompt length - n_ctx - 3 (SOS, '.', EOT), i.e. `len(_tokenizer.encode(name))` (:99)."""
-        assert class_token_position in ("end", "middle", "front"), class_token_position    # `else: raise ValueError`, :185
-        n, L = self.cfg.n_cls, self.Lmax
-        src = np.tile(np.arange(L, dtype=np.int64), (n, 1))
-        ctx_pos = np.zeros((n, n_ctx), dtype=np.int64)
-        half = n_ctx // 2
-        for c in range(n):
-            nl = int(self.len_np[c]) - n_ctx - 3
-            assert nl >= 1, "tokens must be the ids of the 'X X .. name.' prompts with n_ctx placeholders"
-            name = np.arange(1 + n_ctx, 1 + n_ctx + nl)
-            if class_token_position == "end":
-                cp = np.arange(1, 1 + n_ctx)
-            elif class_token_position == "middle":
-                cp = np.concatenate([np.arange(1, 1 + half), np.arange(1 + half + nl, 1 + n_ctx + nl)])
-                src[c, 1 + half:1 + half + nl] = name
-            else:
-                cp = np.arange(1 + nl, 1 + nl + n_ctx)
-                src[c, 1:1 + nl] = name
-            src[c, cp] = -1
-            ctx_pos[c] = cp
-        return src, ctx_pos
-
-    def coop_setup(self, n_ctx: int, replicas: int = 1, meta_hidden: int = 0, csc: bool = False,
-                   class_token_position: str = "end") -> None:
-        """Buffers of the sibling trainers CoOp (trainers/coop.py) and CoCoOp (trainers/cocoop.py): the learned context
-        `coop_ctx` [n_ctx, d_t] and, per text block, everything the DENSE text-tower backward re-reads -- the gradient of a
-        context vector flows through every token of every class (plain causal mask), unlike RPO's prompts.
-        `replicas` > 1 (CoCoOp): the class set is run once per IMAGE with that image's shifted context, i.e. as
-        replicas * n_cls virtual classes; `meta_hidden` > 0 adds the meta-net (linear1 [h, e], linear2 [d_t, h]).  All
-        trained tensors live in one flat fp32 buffer (`coop_params` = [ctx | w1 | b1 | w2 | b2]) with matching gradient
-        and momentum buffers: one SGD launch.  n_cls * Lmax rows per replica (a few hundred), so this is small."""
-        cfg, dev, act = self.cfg, self.dev, self.act
-        n, L, dt, e = cfg.n_cls, self.Lmax, cfg.d_t, cfg.embed
-        assert 1 + n_ctx < self.Lmax and self.Lmax <= 80, "tokens must be the ids of the 'X X .. name.' prompts"
-        assert 1 <= replicas <= self.max_batch
-        nv = replicas * n
-        Rf = nv * L
-        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        a = lambda *s: torch.empty(*s, dtype=act, device=dev)
-        au = f32 if act == torch.float32 else a
-        Lt, h = cfg.layers_t, meta_hidden
-        self.coop_n_ctx, self.coop_replicas, self.coop_hidden = n_ctx, replicas, h
-        # class-specific contexts (TRAINER.COOP.CSC, trainers/coop.py:84-86): ctx [n_cls, n_ctx, d_t] instead of one
-        # [n_ctx, d_t] expanded over the classes (:119-121) -- no sum over the classes in the backward
-        assert not (csc and (replicas > 1 or h)), "class-specific contexts are CoOp's (CoCoOp's context is generic)"
-        self.coop_csc, self.coop_position = bool(csc), class_token_position
-        nctx_rows = (n if csc else 1) * n_ctx
-        src, ctx_pos = self.coop_layout(n_ctx, class_token_position)
-        rows = np.arange(n)[:, None] * L
-        # gather map of the token embeddings (context slots read row 0 and are overwritten) and the rows / positions of
-        # the context vectors, class-major
-        self.c_src_rows = torch.as_tensor((rows + np.maximum(src, 0)).reshape(-1), device=dev)
-        self.c_ctx_rows_idx = torch.as_tensor((rows + ctx_pos).reshape(-1), device=dev)
-        self.c_ctx_pos = torch.as_tensor(ctx_pos.reshape(-1), device=dev)
-        sizes = [nctx_rows * dt] + ([h * e, h, dt * h, dt] if h else [])
-        tot = sum(sizes)
-        self.coop_params = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.coop_grads = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.coop_moms = torch.zeros(tot, dtype=torch.float32, device=dev)
-        offs = np.cumsum([0] + sizes)
-        view = lambda buf, i, *shape: buf[offs[i]:offs[i + 1]].view(*shape)
-        cshape = (n, n_ctx, dt) if csc else (n_ctx, dt)
-        self.coop_ctx, self.coop_grad = view(self.coop_params, 0, *cshape), view(self.coop_grads, 0, *cshape)
-        if h:
-            shapes = [(h, e), (h,), (dt, h), (dt,)]
-            self.meta = [view(self.coop_params, i + 1, *sh) for i, sh in enumerate(shapes)]          # w1, b1, w2, b2
-            self.meta_grad = [view(self.coop_grads, i + 1, *sh) for i, sh in enumerate(shapes)]
-            self.c_fn, self.c_hid, self.c_bias, self.c_dbias = f32(replicas, e), f32(replicas, h), f32(replicas, dt), f32(replicas, dt)
-        self.c_shift = f32(replicas, nctx_rows, dt)                   # the context each replica's classes carry
-        self.c_dshift = f32(replicas, nctx_rows, dt)
-        self.c_len = self.len_i32.repeat(replicas).contiguous()
-        self.cx = [f32(Rf, dt) for _ in range(Lt + 1)]
-        self.cxm = [f32(Rf, dt) for _ in range(Lt)]
-        self.cqkv = [a(Rf, 3 * dt) for _ in range(Lt)]
-        self.cu = [au(Rf, 4 * dt) for _ in range(Lt)]
-        self.ch, self.catt, self.cg = a(Rf, dt), a(Rf, dt), a(Rf, 4 * dt)
-        self.c_dxa, self.c_dxb = f32(Rf, dt), f32(Rf, dt)
-        self.c_dxc, self.c_da = a(Rf, dt), a(Rf, dt)
-        self.c_du, self.c_dqkv = a(Rf, 4 * dt), a(Rf, 3 * dt)
-        self.c_dy = f32(max(SPLIT_FC, SPLIT_Q), Rf, dt)
-        self.c_eot = torch.arange(nv, device=dev) * L + (self.c_len.to(torch.int64) - 1)          # EOT row of every class
-        self.c_x_eot, self.c_dx_eot, self.c_dy_eot = f32(nv, dt), f32(nv, dt), f32(nv, dt)
-        self.c_y_eot = a(nv, dt)
-        self.c_text_f, self.c_d_text_f = f32(nv, e), f32(nv, e)
-        self.c_d_text_f_a = a(nv, e)
-        self.c_d_img_f = f32(self.max_batch, e)
-        self.c_loss_b = f32(self.max_batch)
-        self.c_ctx_rows = f32(nv * n_ctx, dt)
-        if self.img_cls_f is None:
-            self.img_cls_f = torch.empty(self.max_batch, e, dtype=torch.float32, device=dev)
-        # dX of the packed in-projection needs the whole W_in transposed ([d, 3d]); RPO's backward only its q third
-        self.c_w_in_t = [blk.w_in.t().contiguous() for blk in self.txt]
-
-    def _coop_text_forward(self, train: bool, R: int = 1) -> None:
-        """TextEncoder.forward of trainers/coop.py:47-58 on prompts = [SOS | ctx | class name . EOT] (:117-134): all
-        tokens up to the longest EOT, plain causal mask, every block's inputs kept for the backward.  R replicas of the
-        class set, replica r carrying the context c_shift[r] (CoOp: one replica, the context itself)."""
-        cfg = self.cfg
-        n, L, dt, H, nc = cfg.n_cls, self.Lmax, cfg.d_t, cfg.heads_t, self.coop_n_ctx
-        nv = R * n
-        Rf = nv * L
-        x0 = self.cx[0][:Rf]
-        if self.coop_position == "end" and not self.coop_csc:
-            x0.view(R, n * L, dt).copy_(self.text_x_frozen.view(1, n * L, dt).expand(R, -1, -1))
-            x0.view(R, n, L, dt)[:, :, 1:1 + nc] = (self.c_shift[:R] + self.text_pos[1:1 + nc]).unsqueeze(1)
-        else:
-            # prompts = cat([prefix, ctx / class name in the configured order, suffix]) (trainers/coop.py:117-183), then
-            # + positional_embedding by position (TextEncoder.forward, :48)
-            tokpos = torch.index_select(self.text_tok, 0, self.c_src_rows).view(n, L, dt) + self.text_pos
-            x0.view(R, n * L, dt).copy_(tokpos.view(1, n * L, dt).expand(R, -1, -1))
-            cpos = self.text_pos.index_select(0, self.c_ctx_pos)                                  # [n * nc, dt]
-            cs = self.c_shift[:R]
-            vals = (cs if self.coop_csc else cs.unsqueeze(1).expand(R, n, nc, dt).reshape(R, n * nc, dt)) + cpos
-            for r in range(R):
-                x0[r * n * L:(r + 1) * n * L].index_copy_(0, self.c_ctx_rows_idx, vals[r])
-        ch, catt, cg, ln = self.ch[:Rf], self.catt[:Rf], self.cg[:Rf], self.c_len[:nv]
-        for l, blk in enumerate(self.txt):
-            x, xm, qkv = self.cx[l][:Rf], self.cxm[l][:Rf], self.cqkv[l][:Rf]
-            ops.layernorm_fwd(x, blk.ln1_w, blk.ln1_b, ch)
-            ops.gemm_nt(ch, blk.w_in, qkv, EPI_BIAS, bias=blk.b_in)
-            ops.text_attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], catt, ln, nv, L, L, H, causal=True, scale=SCALE)
-            ops.gemm_nt(catt, blk.w_out, xm, EPI_BIAS_RESID, bias=blk.b_out, resid=x)
-            ops.layernorm_fwd(xm, blk.ln2_w, blk.ln2_b, ch)
-            ops.gemm_nt(ch, blk.w_fc, cg, EPI_BIAS_QGELU, bias=blk.b_fc, aux=self.cu[l][:Rf] if train else None,
-                        aux_row0=0 if train else Rf)
-            ops.gemm_nt(cg, blk.w_proj, self.cx[l + 1][:Rf], EPI_BIAS_RESID, bias=blk.b_proj, resid=xm)
-        torch.index_select(self.cx[-1], 0, self.c_eot[:nv], out=self.c_x_eot[:nv])        # feature at the EOT token
-        ops.layernorm_fwd(self.c_x_eot[:nv], self.ln_final[0], self.ln_final[1], self.c_y_eot[:nv])
-        ops.gemm_nt(self.c_y_eot[:nv], self.text_proj_t, self.c_text_f[:nv], EPI_NONE)
-
-    def _coop_text_backward(self, R: int = 1) -> None:
-        """c_dshift[r] = d loss / d (context of replica r): autograd of the whole text tower for all tokens (dX GEMMs only
-        -- the weights are frozen), the causal attention backward with dK / dV (rpo_text_attn_bwd_dense), then the rows of
-        the context positions summed over the classes (ctx.unsqueeze(0).expand, trainers/coop.py:119-121)."""
-        cfg = self.cfg
-        n, L, dt, H, nc = cfg.n_cls, self.Lmax, cfg.d_t, cfg.heads_t, self.coop_n_ctx
-        nv = R * n
-        Rf = nv * L
-        f32m = self.act == torch.float32
-        dxa, dxb, dxc, dy = self.c_dxa[:Rf], self.c_dxb[:Rf], self.c_dxc[:Rf], self.c_dy[:, :Rf]
-        du, da, dq, ln = self.c_du[:Rf], self.c_da[:Rf], self.c_dqkv[:Rf], self.c_len[:nv]
-        ops.gemm_nt(self.c_d_text_f[:nv] if f32m else self.c_d_text_f_a[:nv], self.text_proj, self.c_dy_eot[:nv], EPI_NONE)
-        ops.layernorm_bwd(self.c_dy_eot[:nv], self.c_x_eot[:nv], self.ln_final[0], None, self.c_dx_eot[:nv])
-        dxa.zero_()
-        dxa.index_copy_(0, self.c_eot[:nv], self.c_dx_eot[:nv])
-        if not f32m:
-            ops.convert(dxa, dxc)
-        for l in reversed(range(len(self.txt))):
-            blk, qkv = self.txt[l], self.cqkv[l][:Rf]
-            ops.gemm_nt(dxa if f32m else dxc, blk.w_proj_t, du, EPI_QGELU_BWD, aux=self.cu[l][:Rf])
-            ops.gemm_nt(du, blk.w_fc_t, dy[:SPLIT_FC], EPI_NONE, split_k=SPLIT_FC)
-            ops.layernorm_bwd(dy[:SPLIT_FC], self.cxm[l][:Rf], blk.ln2_w, dxa, dxb, None if f32m else dxc)
-            ops.gemm_nt(dxb if f32m else dxc, blk.w_out_t, da, EPI_NONE)
-            ops.text_attn_bwd_dense(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], da, dq[:, :dt], dq[:, dt:2 * dt],
-                                    dq[:, 2 * dt:], ln, nv, L, H, SCALE)
-            ops.gemm_nt(dq, self.c_w_in_t[l], dy[:SPLIT_Q], EPI_NONE, split_k=SPLIT_Q)
-            ops.layernorm_bwd(dy[:SPLIT_Q], self.cx[l][:Rf], blk.ln1_w, dxb, dxa, None if f32m else dxc)
-        rows = self.c_ctx_rows[:nv * nc]
-        if self.coop_position == "end" and not self.coop_csc:
-            rows.view(nv, nc, dt).copy_(dxa.view(nv, L, dt)[:, 1:1 + nc])
-        else:
-            for r in range(R):          # the rows the context vectors sat in, class-major
-                torch.index_select(dxa[r * n * L:(r + 1) * n * L], 0, self.c_ctx_rows_idx, out=rows[r * n * nc:(r + 1) * n * nc])
-        if self.coop_csc:               # every class has its own vectors: nothing to sum
-            self.c_dshift[0].copy_(rows[:n * nc])
-            return
-        for r in range(R):              # reduce_groups sums `groups` consecutive blocks of `rows` rows: the classes
-            ops.reduce_groups(rows[r * n * nc:(r + 1) * n * nc], self.c_dshift[r], n)
-
-    def _plain_image_features(self, image: torch.Tensor) -> int:
-        cfg = self.cfg
-        B = image.shape[0]
-        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and B <= self.max_batch
-        assert image.device == self.dev and torch.cuda.current_device() == self.dev.index
-        N, dv = cfg.n_frozen, cfg.d_v
-        self._image_forward(image, train=False, full_last=True)
-        cls_rows = self.x[-1][:B * N].view(B, N, dv)[:, 0, :]
-        ops.layernorm_fwd(cls_rows, self.ln_post[0], self.ln_post[1], self.y_post[:B])
-        ops.gemm_nt(self.y_post[:B], self.img_proj_t, self.img_cls_f[:B], EPI_NONE)
-        return B
-
-    def coop_forward_backward(self, image: torch.Tensor, label: Optional[torch.Tensor]) -> torch.Tensor:
-        """trainers/coop.py:196-208 + :266-270: logits = exp(logit_scale) * normalise(image features of the plain image
-        tower) @ normalise(text features of [SOS | ctx | name . EOT])^T; with `label`, also the mean cross-entropy
-        (self.loss) and d loss / d ctx (self.coop_grad).  Returns self.logits[:B]."""
-        cfg = self.cfg
-        e, n = cfg.embed, cfg.n_cls
-        train = label is not None
-        self.c_shift[0].copy_(self.coop_ctx.view(-1, cfg.d_t))
-        # the two towers are independent until the head: the (small, latency-bound) dense text forward runs on the side
-        # stream under the image tower, as RPO's text chain does (RPO_COOP_SERIAL=1: one stream)
-        if os.environ.get("RPO_COOP_SERIAL") == "1":
-            self._coop_text_forward(train)
-            B = self._plain_image_features(image)
-        else:
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self._coop_text_forward(train)
-            B = self._plain_image_features(image)
-            main.wait_stream(self.side)
-        extra = {} if (not train or self.act == torch.float32) else dict(d_text_f_act=self.c_d_text_f_a[:n])
-        ops.head_fwd_bwd(self.img_cls_f[:B].view(B, 1, e), self.c_text_f[:n].view(n, 1, e), label, self.logit_scale_exp,
-                         self.logits[:B], self.loss if train else None,
-                         self.c_d_img_f[:B].view(B, 1, e) if train else None,
-                         self.c_d_text_f[:n].view(n, 1, e) if train else None, self.head_ws, **extra)
-        if train:
-            self._coop_text_backward()
-            self.coop_grad.view(-1, cfg.d_t).copy_(self.c_dshift[0])
-        return self.logits[:B]
-
-    def cocoop_forward_backward(self, image: torch.Tensor, label: Optional[torch.Tensor]) -> torch.Tensor:
-        """trainers/cocoop.py:166-192: image features -> meta-net -> one shifted context per image -> that image's own
-        text features for every class -> logits[b] = exp(logit_scale) * imf_n[b] @ normalise(text_f[b])^T; with `label`
-        the mean cross-entropy (self.loss) and the gradients of ctx and of the four meta-net tensors (self.coop_grads).
-        The batch size is bounded by coop_setup's `replicas` (the reference trains CoCoOp at batch 1:
-        configs/trainers/CoCoOp/vit_b16_c4_ep10_batch1.yaml)."""
-        cfg = self.cfg
-        e, n, nc = cfg.embed, cfg.n_cls, self.coop_n_ctx
-        train = label is not None
-        B = self._plain_image_features(image)
-        assert B <= self.coop_replicas and self.coop_hidden > 0
-        w1, b1, w2, b2 = self.meta
-        ops.metanet_fwd(self.img_cls_f[:B], w1, b1, w2, b2, self.c_fn[:B], self.c_hid[:B], self.c_bias[:B])
-        torch.add(self.coop_ctx.unsqueeze(0), self.c_bias[:B].unsqueeze(1), out=self.c_shift[:B])   # ctx + bias (:141-143)
-        self._coop_text_forward(train, B)
-        f32m = self.act == torch.float32
-        for b in range(B):                  # every image has its own text features: the head runs per image (:183-188)
-            tf = slice(b * n, (b + 1) * n)
-            extra = {} if (not train or f32m) else dict(d_text_f_act=self.c_d_text_f_a[tf])
-            ops.head_fwd_bwd(self.img_cls_f[b:b + 1].view(1, 1, e), self.c_text_f[tf].view(n, 1, e),
-                             label[b:b + 1] if train else None, self.logit_scale_exp, self.logits[b:b + 1],
-                             self.c_loss_b[b:b + 1] if train else None,
-                             self.c_d_img_f[b:b + 1].view(1, 1, e) if train else None,
-                             self.c_d_text_f[tf].view(n, 1, e) if train else None, self.head_ws, **extra)
-        if train:
-            torch.mean(self.c_loss_b[:B], dim=0, keepdim=True, out=self.loss)         # F.cross_entropy: mean over the batch
-            self._coop_text_backward(B)
-            ds = self.c_dshift[:B]
-            ds.mul_(1.0 / B)                                                          # ... and so are its gradients
-            torch.sum(ds, dim=0, out=self.coop_grad)                                  # ctx is shared by all images
-            torch.sum(ds, dim=1, out=self.c_dbias[:B])                                # bias[b] is added to every context row
-            g1, gb1, g2, gb2 = self.meta_grad
-            ops.metanet_bwd(self.c_dbias[:B], self.c_fn[:B], self.c_hid[:B], w2, g1, gb1, g2, gb2)
-        return self.logits[:B]
-
     def forward_backward(self, image: torch.Tensor, label: torch.Tensor) -> None:
         """Enqueue loss + both prompt gradients (trainers/rpo.py:229-230, :308).  Results land in
         self.loss, self.logits, self.grads (= [g_text | g_img]).  Capturable in a HIP graph."""
@@ -1312,3 +926,13 @@ class Engine:
         if not self.text_cache_ready:
             self.cache_text_kv()
         return B
+
+
+def make_engine(*args, **kw) -> Engine:
+    """The engine a model / trainer is built on: `Engine`, or -- only under RPO_EXPERIMENTAL=1, which also selects the
+    -DRPO_EXPERIMENTAL build of the library -- its subclass with the measured-slower experiments (rpo_amd/experimental.py)."""
+    from ._lib import EXPERIMENTAL
+    if EXPERIMENTAL:
+        from .experimental import ExperimentalEngine
+        return ExperimentalEngine(*args, **kw)
+    return Engine(*args, **kw)

@@ -23,7 +23,7 @@ from . import ops
 from .config import RPOConfig
 from .custom_clip import CustomCLIP
 from .dist import GradSync
-from .engine import _xenv
+from ._lib import xenv as _xenv
 
 
 @dataclass
@@ -83,6 +83,7 @@ class RPO:
         self._joint_bwd = False
         self._split_collective = False
         self._graph_collectives = False
+        self._graph_collectives_note = None          # why the collectives are NOT in the graphs, when they are not
         self._text_ar_in_graph = False
         self._tail_graphs = {}
         self.best_result = -float("inf")
@@ -180,8 +181,11 @@ class RPO:
                     self._g_text_bwd = cap(lambda: (eng._text_backward(), self.sync.all_reduce_sum(eng.g_text_flat)))
                     self._text_ar_in_graph = True
                 except Exception as ex:             # noqa: BLE001 -- any capture failure: eager collectives
+                    # the fallback is for the PROCESS GROUP (this trainer's communicator), not for this one call: from here on
+                    # every collective of every step is issued eagerly between the graphs, and the bench line says why
                     print(f"[rpo_amd] capturing the collective failed ({type(ex).__name__}: {ex}); collectives stay eager")
                     self._graph_collectives = False
+                    self._graph_collectives_note = f"capture of the RCCL all-reduce failed ({type(ex).__name__}): eager for this process group"
                     torch.cuda.synchronize()
             if not self._text_ar_in_graph:
                 self._g_text_bwd = cap(eng._text_backward)
@@ -272,6 +276,9 @@ class RPO:
         if src.data_ptr() not in self._g_patch and len(self._g_patch) >= 8:
             if self._image_next is None:
                 self._image_next = torch.zeros_like(self._image)
+            # (the previous step's patch embed may still be READING the staging buffer on the side stream -- at small batches,
+            #  with the early text forward in front of it, it outlives the main stream's backward: the copy goes behind it)
+            torch.cuda.current_stream().wait_event(self._ev_patch)
             self._image_next.copy_(next_image, non_blocking=True)
             src = self._image_next
         g = self._g_patch.get(src.data_ptr())
@@ -413,6 +420,7 @@ class RPO:
                     self._tail_graphs[key] = tail
                 except Exception as ex:             # noqa: BLE001
                     print(f"[rpo_amd] capturing the step's tail failed ({type(ex).__name__}: {ex}); it stays eager")
+                    self._graph_collectives_note = f"capture of the step's tail failed ({type(ex).__name__}): eager for this process group"
                     self._graph_collectives, tail = False, None
                     torch.cuda.synchronize()
         if tail is not None:
@@ -458,8 +466,9 @@ class RPO:
             raise FloatingPointError(f"non-finite values after step {self._steps}: {', '.join(bad)}")
         # experiments only (RPO_EXPERIMENTAL=1): a bounded spin of a persistent launch that gave up leaves results
         # undefined, not non-finite -- its give-up words are part of the scan (advisor, round 4)
-        for name, t, idx in (("rpo_chain_bwd (image)", eng.chain_state_v, 0), ("rpo_chain_bwd (text)", eng.chain_state_t, 0),
-                             ("rpo_mlp_fused", eng.mlp_counters if _xenv("RPO_MLP_FUSED") != "0" else None, -1)):
+        for name, t, idx in (("rpo_chain_bwd (image)", getattr(eng, "chain_state_v", None), 0),
+                             ("rpo_chain_bwd (text)", getattr(eng, "chain_state_t", None), 0),
+                             ("rpo_mlp_fused", getattr(eng, "mlp_counters", None) if _xenv("RPO_MLP_FUSED") != "0" else None, -1)):
             if t is not None and int(t[idx]) != 0:
                 raise RuntimeError(f"{name}: a bounded spin gave up in or before step {self._steps}: the results are undefined")
 

@@ -15,7 +15,7 @@ import torch
 
 from .config import RPOConfig
 from .custom_clip import config_from_state_dict
-from .engine import Engine
+from .engine import Engine, make_engine
 from . import synth
 
 
@@ -32,7 +32,7 @@ class ZeroshotCLIP:
         if cfg is None:
             cfg = config_from_state_dict(state_dict, 1, tokens.shape[0])     # one (unused) prompt row per image
         self.cfg = cfg
-        self.engine = Engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
+        self.engine = make_engine(cfg, state_dict, tokens, torch.device(device), act_dtype, max_batch)
         with torch.cuda.device(self.engine.dev):
             self.engine.cache_text_kv()                                       # text features: once (zsclip.py:48-53)
 

@@ -493,6 +493,63 @@ def test_bench_eight_rank_flow_on_one_gpu():
     assert not glob.glob(os.path.join(tempfile.gettempdir(), "rpo_amd_weights_*")), "shared weight directory left behind"
 
 
+_EDGE_ORACLE = {}
+
+
+def _edge_oracle(K, lens, B, layers_t, seed_sd, seed_p):
+    """(cfg, toks, sd, prompts, image, label, oracle outputs) of an edge-shape case: the dense CPU oracle runs ONCE per
+    case however many storage modes are compared against it (1000 classes x 77 tokens take it tens of seconds)."""
+    from oracle.rpo_oracle import OracleRPO
+    from rpo_amd.config import vit_b16
+    key = (K, tuple(lens), B, layers_t, seed_sd, seed_p)
+    if key not in _EDGE_ORACLE:
+        cfg = vit_b16(layers_v=1, layers_t=layers_t, K=K, n_cls=len(lens))
+        toks = synth.synthetic_tokens(cfg, lens)
+        sd = synth.clip_state_dict(cfg, seed=seed_sd, token_rows=np.unique(toks).tolist() + [49407])
+        tp, ip = synth.prompts(cfg, sd, seed=seed_p)
+        image, label = synth.images(cfg, B), synth.labels(cfg, B)
+        o = OracleRPO(sd, toks, cfg.K, cfg.patch)
+        o.set_prompts(tp, ip)
+        out, gt, gi = o.loss_and_grads(image, label)
+        _EDGE_ORACLE[key] = (cfg, toks, sd, (tp, ip), image, label, float(out.loss.item()), out.logits.detach().numpy().copy(),
+                             gt.numpy().copy(), gi.numpy().copy())
+        del o
+    return _EDGE_ORACLE[key]
+
+
+# the reference's large-class-count workload (configs/trainers/RPO/imagenet_k24_ep15.yaml:1-35 + scripts/rpo/xd_train.sh:20-28:
+# K = 24 on 1000 ImageNet classes; SUN397 has 397): 24 000 prompt rows in the text tower, 19 x 8-14 -> 1000 x 3-24 keys
+MANY_CLASS_LENS = {n: [3 + (7 * c) % 22 for c in range(n)] for n in (100, 397, 1000)}
+
+
+@pytest.mark.parametrize("n_cls", [100, 397, 1000])
+@pytest.mark.parametrize("act", [torch.float32, torch.float16, torch.bfloat16], ids=["float32", "float16", "bfloat16"])
+def test_many_classes_k24_against_oracle(n_cls, act):
+    """K = 24 prompts over 100 / 397 / 1000 classes (the reference trains RPO on ImageNet's 1000: the text tower is then
+    24 000 prompt rows, 2.3x the image tower's FLOPs -- the inverse of the Oxford-Pets bench): loss, both prompt gradients
+    and the eval logits against the dense CPU oracle at depth 1, in every storage mode, through the kernels the engine
+    selects at that size (rpo_gemm_nt's wide tiles from 2048 rows on, the three-launch head, 8000 attention waves)."""
+    from rpo_amd.custom_clip import CustomCLIP
+    cfg, toks, sd, prm, image, label, o_loss, o_logits, gt, gi = _edge_oracle(24, MANY_CLASS_LENS[n_cls], 2, 1, 5, 13)
+    m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=2, prompts=prm)
+    loss = m(torch.from_numpy(image).cuda(), torch.from_numpy(label).cuda())
+    loss.backward()
+    rt = _relmax(m.prompt_learner.text_prompt.grad.cpu().numpy(), gt)
+    ri = _relmax(m.prompt_learner.img_prompt.grad.cpu().numpy(), gi)
+    m.prompt_learner.eval()
+    le = float(np.abs(m(torch.from_numpy(image).cuda()).cpu().numpy() - o_logits).max())
+    print(f"[{act} n_cls={n_cls} K=24] loss err {abs(loss.item() - o_loss):.3e} logits err {le:.3e} g_text rel {rt:.3e} g_img rel {ri:.3e}")
+    if act == torch.float32:
+        assert abs(loss.item() - o_loss) <= TOL_F32 and rt <= TOL_F32 and ri <= TOL_F32 and le <= TOL_F32
+    else:
+        la, gr = (F16_LOGIT_ATOL, F16_GRAD_REL) if act == torch.float16 else (BF16_LOGIT_ATOL, BF16_GRAD_REL)
+        # (logits: the modes' bounds were set on |logits| <= 8.7 -- 19 classes; over 1000 classes the largest logit is 12.0 and
+        #  the maximum runs over 2000 of them: the bound scales with the logits' magnitude, as in the 300-class edge case below.
+        #  Measured at 1000 classes: f16 1.05e-2, i.e. 8.7e-4 of the largest logit)
+        scale = max(1.0, float(np.abs(o_logits).max()) / 8.7)
+        assert abs(loss.item() - o_loss) <= la and rt <= gr and ri <= gr and le <= la * scale
+
+
 @pytest.mark.parametrize("K,n_cls,B", [(1, 19, 2), (5, 40, 3), (53, 3, 1), (4, 300, 2)])
 def test_edge_shapes_against_oracle_f32(K, n_cls, B):
     """K = 1 (reference asserts K >= 1), a class count that is not 19, the largest K that still fits the

@@ -524,3 +524,20 @@ def test_golden_manifest_matches_the_committed_fixtures():
         path = os.path.join(gold, f"ref_{name}.npz")
         assert os.path.exists(path), path
         assert os.path.getsize(path) == rec["bytes"], (name, os.path.getsize(path), rec["bytes"])
+
+
+def test_default_import_path_touches_no_experimental_code():
+    """The product engine reads none of the experiments' switches and the default import path never loads
+    rpo_amd/experimental.py (it subclasses Engine and is imported by engine.make_engine under RPO_EXPERIMENTAL=1 only)."""
+    import subprocess
+    code = ("import sys, rpo_amd.engine, rpo_amd.trainer, rpo_amd.custom_clip, rpo_amd.coop, rpo_amd.zeroshot;"
+            "assert 'rpo_amd.experimental' not in sys.modules; print('clean')")
+    env = {k: v for k, v in os.environ.items() if k != "RPO_EXPERIMENTAL"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
+    src = open(os.path.join(ROOT, "rpo_amd", "engine.py")).read()
+    exp_switches = ("RPO_CHAIN", "RPO_MLP_FUSED", "RPO_JOINT_BWD", "RPO_TEXT_BWD_FOLD", "RPO_BWD_PARTS", "RPO_BWD_FOLD_R3")
+    code_only = "\n".join(line.split("#", 1)[0] for line in src.splitlines())
+    for name in exp_switches:
+        assert f'"{name}"' not in code_only, f"engine.py reads the experiment switch {name}"
+    assert "xenv" not in code_only and len(src.splitlines()) <= 1000

@@ -41,4 +41,6 @@ for name, B, H, N, Kp, gain in (("ViT-B/16 B=32", 32, 12, 197, 24, 1.0), ("ViT-B
     got = torch.cat([out[:B * N].view(B, N, d), out[B * N:].view(B, Kp, d)], 1).double()
     err = (got - ref).abs().max().item()
     flops = 4.0 * B * H * S * N * 64
-    print(f"{name:28s} {str(dt)[6:]:9s} {best:7.2f} us  {flops / best * 1e-6:7.1f} TFLOP/s  max abs err {err:.2e} (|out| <= {ref.abs().max().item():.2f})")
+    import hashlib
+    sha = hashlib.sha1(out.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:10]
+    print(f"{name:28s} {str(dt)[6:]:9s} {best:7.2f} us  {flops / best * 1e-6:7.1f} TFLOP/s  max abs err {err:.2e} (|out| <= {ref.abs().max().item():.2f}) sha1 {sha}")

@@ -46,9 +46,20 @@ SHAPES = [  # name, M, N, K, epi, out dtype, split
     ("b16_out", 3536, 768, 768, EPI_BIAS_RESID, torch.float32, 1),
     ("b16_fc", 3536, 3072, 768, EPI_BIAS_QGELU, torch.bfloat16, 1),
     ("b16_proj", 3536, 768, 3072, EPI_BIAS_RESID, torch.float32, 1),
+    # the text tower at 1000 classes x K = 24 (configs/trainers/RPO/imagenet_k24_ep15.yaml): 24 000 prompt rows
+    ("t1k_q", 24000, 512, 512, EPI_BIAS, torch.bfloat16, 1),
+    ("t1k_out", 24000, 512, 512, EPI_BIAS_RESID, torch.float32, 1),
+    ("t1k_fc", 24000, 2048, 512, EPI_BIAS_QGELU, torch.bfloat16, 1),
+    ("t1k_proj", 24000, 512, 2048, EPI_BIAS_RESID, torch.float32, 1),
+    ("t1k_du", 24000, 2048, 512, EPI_QGELU_BWD, torch.bfloat16, 1),
+    ("t1k_dh2", 24000, 512, 2048, EPI_NONE, torch.float32, 1),
+    ("t1k_dh2", 24000, 512, 2048, EPI_NONE, torch.float32, 3),
+    ("t1k_dh1", 24000, 512, 512, EPI_NONE, torch.float32, 1),
+    ("t1k_dh1", 24000, 512, 512, EPI_NONE, torch.float32, 2),
+    ("t1k_da", 24000, 512, 512, EPI_NONE, torch.bfloat16, 1),
 ]
 for name, M, N, K, epi, odt, split in SHAPES:
-    if ONLY is not None and name != ONLY:
+    if ONLY is not None and name != ONLY and not (ONLY.endswith("*") and name.startswith(ONLY[:-1])):
         continue
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
