@@ -310,7 +310,7 @@ def committed_step_traffic(args):
     """HBM bytes per step from the committed rocprofv3 PMC summary (profiles/rNN_step_hbm_traffic.txt: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, 2*FETCH + WRITE per MI355X_MICROARCH.md).  bench.py
     cannot collect counters itself, so the number is only attached for the workload it was measured on."""
-    if (args.model, args.K, args.batch, args.dtype, args.no_graph, args.n_cls) != ("ViT-B/16", 24, 32, "bf16", False, 19):
+    if (args.model, args.K, args.batch, args.dtype, args.no_graph, getattr(args, "n_cls", 19)) != ("ViT-B/16", 24, 32, "bf16", False, 19):
         return None, None
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
@@ -342,7 +342,7 @@ def committed_qkv_gemm(args):
     """The north-star kernel figure (BASELINE.json: >= 70 % MFMA utilisation on the masked-attention QKV GEMM) from the
     committed PMC summary of the same profile refresh as the traffic figure (profiles/rNN_gemm_pmc.txt; bench.py cannot
     collect counters), under the same guard: attached only while rpo_amd/csrc hashes to what that refresh recorded."""
-    if (args.model, args.K, args.batch, args.dtype, args.n_cls) != ("ViT-B/16", 24, 32, "bf16", 19):
+    if (args.model, args.K, args.batch, args.dtype, getattr(args, "n_cls", 19)) != ("ViT-B/16", 24, 32, "bf16", 19):
         return None
     import glob
     here = os.path.dirname(os.path.abspath(__file__))

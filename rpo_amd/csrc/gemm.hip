@@ -1000,7 +1000,10 @@ int launch(const GemmParams& p, hipStream_t s) {
   if constexpr (sizeof(TIn) == 2) {
     if (p.force_cfg == 9) return launch_cfg<TIn, TOut, EPI, CfgQuad>(p, s);
   }
-  if (p.force_cfg == 6 || (p.force_cfg == 0 && p.N <= RPO_TALL_N)) return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
+  // ... up to 8192 rows: from there on (the text tower over hundreds of classes: 24 000 prompt rows at ImageNet's 1000) the
+  // 64x128 tiles' DMA bytes lose to 128x128 (tools/bench_gemm.py --only "t1k_*", profiles/r06_bench_gemm_t1k.txt: q-proj
+  // 26.8 -> 23.6 us, c_proj 75.6 -> 68.4, d c_fc 71.2 -> 64.0 at 24 000 x 512)
+  if (p.force_cfg == 6 || (p.force_cfg == 0 && p.N <= RPO_TALL_N && p.M < 8192)) return launch_cfg<TIn, TOut, EPI, CfgTall>(p, s);
   return launch_cfg<TIn, TOut, EPI, CfgMid>(p, s);
 }
 

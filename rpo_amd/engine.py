@@ -110,6 +110,15 @@ class Engine(CoopEngineMixin):
         # dproj, dfc, dq: backward) on top of the two defaults above
         self._text_tiles = dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("RPO_WS_TEXT_TILES", "").split(",") if kv))
         self._ws_text_cfg_bwd = int(os.environ.get("RPO_WS_TEXT_CFG_BWD", os.environ.get("RPO_WS_TEXT_CFG", "120" if big else "0")))
+        # Thousands of text rows (ImageNet's 1000 classes x K = 24: the reference's xd_train.sh): c_fc saves the QuickGELU
+        # derivative of EVERY row, which the 256x256 kernel's generic epilogue does in a second pass (131 us per launch
+        # against 69 without, profiles/r06_trace_ncls1000.txt); the row-unit kernel forms it in its block loop.  It takes
+        # row units that tile the rows in whole rounds of the CUs: u rows each with 225 <= u <= 288 and (rows / u) x
+        # (4 d_t / 256) a multiple of 256 -- 250 at 24 000 rows.  No such u: the heuristic's choice stays.
+        Rt_, tn = cfg.n_cls * cfg.K, (4 * cfg.d_t) // 256
+        u = next((u for u in range(288, 224, -1) if Rt_ % u == 0 and ((Rt_ // u) * tn) % 256 == 0), 0)
+        self._text_fc_units = (dict(row_units=(u, 0, Rt_)) if (u and Rt_ >= 2048 and act_dtype != torch.float32
+                                                                 and os.environ.get("RPO_NO_TEXT_UNITS") != "1") else {})
         tokens = np.asarray(tokens, dtype=np.int64)
         assert tokens.shape == (cfg.n_cls, cfg.context)
         self.len_np = tokens.argmax(-1) + 1             # trainers/rpo.py:137
@@ -425,7 +434,7 @@ class Engine(CoopEngineMixin):
             if fold:
                 self._gemm(self.ht, blk.w_fc_ln, self.gt, EPI_LN_BIAS_QGELU, bias=blk.b_fc_ln,
                             aux=self.ut[l] if train else None, aux_row0=0, ln_stats=st, ln_colsum=blk.s_fc,
-                            prefetch=blk.w_proj if pf else None, **self._tt("fc"))
+                            prefetch=blk.w_proj if pf else None, **self._tt("fc"), **self._text_fc_units)
             else:
                 ops.layernorm_fwd(self.xtm[l], blk.ln2_w, blk.ln2_b, self.ht)
                 self._gemm(self.ht, blk.w_fc, self.gt, EPI_BIAS_QGELU, bias=blk.b_fc,
@@ -685,9 +694,10 @@ class Engine(CoopEngineMixin):
             #  step 1.8 % SLOWER, 3.045 vs 2.992 ms; the saved QuickGELU operand u[l-1], named by the d q-proj GEMM: no
             #  effect, 2.875 vs 2.871 ms)
             self._gemm(a_in, blk.w_proj_t, du, EPI_QGELU_BWD, aux=u[l], prefetch=blk.w_fc_t if pf else None, **tc("dproj"))  # d c_proj, d QuickGELU
-            self._gemm(du, blk.w_fc_t, dy[:s_fc], EPI_NONE, split_k=s_fc,
+            dyf = dy[0] if s_fc == 1 else dy[:s_fc]
+            self._gemm(du, blk.w_fc_t, dyf, EPI_NONE, split_k=s_fc,
                        prefetch=self._oq_hint(blk, fold_out, ws) if pf else None, **tc("dfc"))    # d c_fc
-            ops.layernorm_bwd(dy[:s_fc], xm[l], blk.ln2_w, dxa, dxb,
+            ops.layernorm_bwd(dyf, xm[l], blk.ln2_w, dxa, dxb,
                               None if self.act == torch.float32 else dxc)
             a_in = dxb if self.act == torch.float32 else dxc
             if fold_out:

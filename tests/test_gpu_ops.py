@@ -951,7 +951,9 @@ def test_text_attn_fwd_bwd(mode, lens, Kr):
 
 
 @pytest.mark.parametrize("B,C,K,e", [(4, 19, 24, 512), (32, 19, 24, 512), (100, 37, 16, 512), (5, 128, 8, 768),
-                                     (3, 300, 4, 768), (1, 2, 1, 64), (7, 3, 5, 100)])
+                                     (3, 300, 4, 768), (1, 2, 1, 64), (7, 3, 5, 100),
+                                     # the three-launch path at the reference's ImageNet size and just past the fused path's 128
+                                     (32, 1000, 24, 512), (2, 129, 1, 768)])
 def test_head_fwd_bwd(B, C, K, e):
     o = ops()
     i_f, t_f = rnd((B, K, e), 31), rnd((C, K, e), 32)
@@ -1075,6 +1077,23 @@ def test_sgd_broadcast_reduce_convert():
     for gidx in range(32):                      # same fixed order as the kernel: bit-exact
         acc += big[gidx * 24:(gidx + 1) * 24]
     assert torch.equal(out.cpu(), acc)
+    # >= 64 groups (the text gradient over hundreds of classes): 8 strided partial sums per element, added in thread-row
+    # order -- the same fixed order here, bit-exact; odd widths and group counts that do not divide by 8
+    for groups, rows, d in ((1000, 24, 512), (397, 5, 100), (64, 3, 33)):
+        big = rnd((groups * rows, d), 45 + groups)
+        out = torch.empty(rows, d, device=dev())
+        o.reduce_groups(big.to(dev()), out, groups)
+        parts = []
+        for j in range(8):
+            a = torch.zeros(rows, d)
+            for gidx in range(j, groups, 8):
+                a += big[gidx * rows:(gidx + 1) * rows]
+            parts.append(a)
+        acc = parts[0].clone()
+        for j in range(1, 8):
+            acc += parts[j]
+        assert torch.equal(out.cpu(), acc), (groups, rows, d)
+    big = rnd((32 * 24, 768), 44)
     c = torch.empty(24, 768, dtype=torch.bfloat16, device=dev())
     o.convert(big[:24].to(dev()), c)
     assert torch.equal(c.cpu(), big[:24].to(torch.bfloat16))

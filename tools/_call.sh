@@ -1,12 +1,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/c4; mkdir -p $O
-for v in default onebar oldattn; do
-  if [ $v = default ]; then unset RPO_HIP_LIB; else export RPO_HIP_LIB=$PWD/rpo_amd/build/ab/librpo_$v.so; fi
-  echo "== $v" >> $O/bench_attn.txt
-  timeout 120 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids >> $O/bench_attn.txt
-done
-unset RPO_HIP_LIB
-timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "attn" 2>&1 | tail -5 > $O/pytest_attn.txt
-timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -k "early_patch or one_graph or two_rank_flow or eight_rank or many_classes or graph_replay or golden" 2>&1 | tail -30 > $O/pytest_sel.txt
-bash tools/ab_libs.sh "" default default:RPO_NO_RESID_HINT=1 onebar oldattn lazy tpi2 > $O/ab_libs.txt 2>&1
-cat $O/bench_attn.txt $O/pytest_attn.txt $O/pytest_sel.txt $O/ab_libs.txt
+O=gpurun_out/c8; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -m gpu -q -k "many_classes or edge_shapes or reduce or head" 2>&1 | tail -12 > $O/pytest_sel.txt
+timeout 600 python bench.py --n-cls 1000 --steps 20 --warmup 5 --no-cpu-baseline --no-f16-sibling --no-precision 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ncls1000', d['ms_per_step'], d['value'], d['roofline']['frac'])" >> $O/ncls1000.txt
+timeout 600 python bench.py --n-cls 100 --steps 30 --warmup 5 --no-cpu-baseline --no-f16-sibling --no-precision 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ncls100', d['ms_per_step'], d['value'], d['roofline']['frac'])" >> $O/ncls1000.txt
+timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $O/trace1000 -o t -- python bench.py --n-cls 1000 --steps 6 --warmup 2 --no-cpu-baseline --no-precision --no-f16-sibling > $O/bench_traced1000.json 2> $O/trace1000.err
+python tools/prof_stats.py $(find $O/trace1000 -name "*_results.db" | head -1) 30 > $O/trace1000_stats.txt 2>&1
+rm -rf $O/trace1000
+cat $O/pytest_sel.txt $O/ncls1000.txt; grep -i "head\|reduce" $O/trace1000_stats.txt

@@ -18,10 +18,12 @@ dev = torch.device("cuda:0")
 buf = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
 assert lib.rpo_debug_set_timeline(buf.data_ptr()) == 0
 H, N, Kp, d = 12, 197, 24, 768
-# stamps 4 / 5 exist only in the -DRPO_ATTN_FWD_V2 variant (scores of a whole query tile in registers); the shipped
-# online-softmax kernel goes from "barrier passed" straight to "key loop + stores issued": absent stamps are skipped
-names = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "S^T done", "softmax done",
-         "key loop (S^T, softmax, P.V) + stores issued", "stores drained"]
+# round 6 (attn_fwd16_kernel, the 16-bit modes' default): two-phase staging -- stamps 1 / 2 = V^T fragments written / the
+# first 128 K rows committed, 3 = barrier A passed, 4 = key tiles 0 .. 3 done, 5 = rest of K committed + barrier B passed,
+# 6 = remaining key tiles + partial tile + stores issued.  (The one-barrier kernel -- f32 mode, -DRPO_ATTN_ONE_BARRIER --
+# has no stamps 4 / 5: absent stamps are skipped.)
+names = ["start", "q + V landed, V^T built", "K rows [0,128) committed", "barrier A passed", "key tiles 0-3 (phase A)",
+         "rest of K committed, barrier B passed", "remaining key tiles + stores issued", "stores drained"]
 for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
     qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
     out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
