@@ -326,7 +326,9 @@ __device__ __forceinline__ void contract_keys(const char* m_lds, int t, const f3
 //    than TAU = 8 in log2 units.  Measured (profiles/r06_attn_variants.txt): kernel 15.6 vs 16.0 us, step -0.4 %; but the
 //    largest weight of a row is then no longer exactly 1.0 in the 16-bit P, and the op's max abs error grows 1.7x (bf16
 //    6.6e-3 vs 3.8e-3 on |out| <= 1.3; model-level logits error unchanged) -- not worth a looser op-level bound.
+#ifdef RPO_ATTN_LAZY
 constexpr float ATTN_TAU = 8.0f;
+#endif
 
 // moves the running maximum m to cover this tile's row maximum tm; returns the factor the running sum / output carry
 template <typename T>
@@ -1383,9 +1385,10 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
   // (B = 32: no CU hosts two whole units any more), but the STEP is 0.5 % slower (2.958 vs 2.943 ms, three alternating
   // pairs) and the forward pair with the text tower beside it unchanged: a grid that fills every resident slot has no
   // room left for the side queue's workgroups, whose hosts then run a third half-unit (profiles/r04_ab_attn_fwd_variants.txt).
-  const int units = B * H, cus = rpo_cu_count();
+  const int units = B * H;
   int nsplit = 0;
 #ifdef RPO_ATTN_SPLIT
+  const int cus = rpo_cu_count();
   if (sizeof(T) == 2 && q_first == 0 && units > cus && units < 2 * cus) nsplit = 2 * cus - units < units ? 2 * cus - units : units;
 #endif
   hipLaunchKernelGGL(kern, dim3(units + nsplit), dim3(512), bytes, s, static_cast<const T*>(q),

@@ -391,6 +391,29 @@ def test_vit_l14_dims_against_oracle(act, tol):
         assert el <= 0.1 and rt <= BF16_GRAD_REL and ri <= BF16_GRAD_REL
 
 
+def test_dry_scale_schedules_agree_under_real_rccl():
+    """`bench.py --dry-scale` (round 6): one GPU, a real RCCL communicator of one rank.  The three ways a rank may issue the
+    step's collectives -- captured in the step's graphs (the N > 1 default: asserted captured), eager between the graphs (the
+    per-process-group fallback), ONE all-reduce after the join (RPO_ONE_COLLECTIVE=1, what gloo uses) -- give bit-identical
+    losses and prompts over five steps across an epoch boundary, and the line carries what the communicator reports."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "RPO_FORCE_DIST")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-scale", "--batch", "4"], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ds = d["dry_scale"]
+    assert ds["ok"] and ds["bit_identical"]
+    assert ds["runs"]["graph"]["collectives_in_graph"] and ds["runs"]["graph"]["text_allreduce_in_graph"]
+    assert ds["runs"]["graph"]["tail_graphs"] >= 2 and not ds["runs"]["eager"]["collectives_in_graph"]
+    assert not ds["runs"]["one_collective"]["split_collective"] and ds["runs"]["graph"]["split_collective"]
+    assert d["rccl_ranks"] == 1 and d["backend"] == "nccl" and len(d["rank_devices"]) == 1 and "rank 0" in d["rank_devices"][0]
+
+
 def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     """The launch line the driver uses for N > 1, with one rank (this box has one GPU): RCCL process group,
     prompt broadcast, gradient all-reduce and barriers all execute (RPO_FORCE_DIST=1)."""
@@ -416,6 +439,10 @@ def test_bench_runs_under_torchrun_with_rccl(tmp_path):
     # round 5: the two all-reduces and the SGD launch are captured in the step's HIP graphs (RCCL under stream capture);
     # the same run with eager collectives (RPO_NO_GRAPH_COLLECTIVES=1) must end at the same loss
     assert d["config"]["collectives_in_graph"] is True and d["config"]["host_us_per_step"] > 0
+    # round 6: what the communicator itself reports, and the collective's DEVICE time (events around graph-replayed all-reduces)
+    assert d["config"]["rccl_ranks"] == 1 and len(d["config"]["rank_devices"]) == 1
+    assert d["config"]["collective_us"] > 0 and "graph replays" in d["config"]["collective_us_how"]
+    assert d["config"]["collective_host_clocked_us"] > 0
     r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, RPO_NO_GRAPH_COLLECTIVES="1"), cwd=root)
     assert r2.returncode == 0, r2.stderr[-2000:]
     d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
@@ -688,8 +715,9 @@ _F32_FULL = {}
 # Full-size fixtures (tools/make_golden_fullsize.py): the REAL reference run on the bench's own shapes (12 layers,
 # B = 32, every K of the configs[4] sweep), so that the model-level comparison goes through the kernels the bench
 # selects -- gemm_w4 / gemm_w4g / gemm_w4k at M = 32 x 221, the K = 48 path -- and not only through the generic tiles
-# that the small-batch goldens reach.  ViT-L/14 (configs[3]) cannot run in the reference (SURVEY.md finding 7); its
-# fixture comes from the dense oracle and is named oracle_*.
+# that the small-batch goldens reach.  ViT-L/14 (configs[3]): the reference's shipped trainer hard-codes four ViT-B/16
+# dimensions (SURVEY.md finding 7); its fixture `ref_full_vitl14_k24_b16` comes from the reference's own CustomCLIP run at
+# L/14 widths with those four values supplied from outside (tools/make_golden_vitl14_ref.py).
 FULL_GOLDEN = [("ref_full_k24_b32", "ViT-B/16", 24, 32), ("ref_full_k4_b32", "ViT-B/16", 4, 32),
                ("ref_full_k8_b32", "ViT-B/16", 8, 32), ("ref_full_k16_b32", "ViT-B/16", 16, 32),
                ("ref_full_k48_b32", "ViT-B/16", 48, 32), ("ref_full_vitl14_k24_b16", "ViT-L/14", 24, 16)]
