@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 7
+#define RPO_ABI_VERSION 8
 
 enum { RPO_F32 = 0, RPO_BF16 = 1, RPO_F16 = 2 };
 
@@ -224,6 +224,14 @@ int rpo_img_assemble(float* x, int64_t ldx, const float* cls, const float* pos0,
 int rpo_img_embed_norm(float* x_pre, int64_t ldx, const float* cls, const float* pos0, const float* img_prompt,
                        const float* g_pre, const float* b_pre, float* x0, int64_t ldx0, const float* g1, const float* b1,
                        void* h, int64_t ldh, int h_dtype, int B, int N, int Kp, int d, float eps, void* stream);
+/* (ABI 8) The same for the token rows [row0, row1) only.  The frozen rows [0, B*N) depend on the batch alone, not on the
+ * prompts (trainers/rpo.py:198-203), so a trainer may form them for the NEXT batch while this step's backward is still
+ * running and run [B*N, B*(N+Kp)) -- the prompt rows -- at the head of the next image forward.  Row by row the bits of
+ * rpo_img_embed_norm. */
+int rpo_img_embed_norm_rows(float* x_pre, int64_t ldx, const float* cls, const float* pos0, const float* img_prompt,
+                            const float* g_pre, const float* b_pre, float* x0, int64_t ldx0, const float* g1,
+                            const float* b1, void* h, int64_t ldh, int h_dtype, int B, int N, int Kp, int d,
+                            float eps, int row0, int row1, void* stream);
 
 /* dst[g*rows + i, :] = src[i, :]  (text prompts written into every class, trainers/rpo.py:176-177) */
 int rpo_broadcast_rows(const float* src, float* dst, int64_t ld, int groups, int rows, int d, void* stream);

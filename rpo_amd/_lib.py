@@ -112,6 +112,8 @@ SIGNATURES = {
     "rpo_im2col_patches": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "rpo_img_embed_norm": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32,
                                    c_i32, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "rpo_img_embed_norm_rows": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32,
+                                        c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "rpo_img_assemble": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "rpo_broadcast_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "rpo_reduce_groups": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),

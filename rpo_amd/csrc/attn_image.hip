@@ -1357,7 +1357,16 @@ int launch_fwd(const void* q, const void* k, const void* v, int64_t ld, void* ou
   if constexpr (sizeof(T) == 2) return launch_fwd2<T, NT>(q, k, v, ld, out, ldo, B, H, N, Kp, scale, q_first, s);
 #endif
 #if !defined(RPO_ATTN_OLD_LOOP) && !defined(RPO_ATTN_ONE_BARRIER) && !defined(RPO_ATTN_SPLIT) && !defined(RPO_ATTN_FWD_2PASS)
-  if constexpr (sizeof(T) == 2) {       // round 6: two-phase staging (A/B build -DRPO_ATTN_ONE_BARRIER: the one-barrier kernel)
+  // round 6: two-phase staging where the launch has more (image, head) units than CUs and seven key tiles (ViT-B/16 from
+  // batch 22 on) -- there the staging burst is long and the early start pays (batch 64: -0.5 % on the step); with fewer
+  // units (or ViT-L/14's nine key tiles, 256 units at batch 16) the second barrier's wave skew costs more than the early start
+  // returns (ViT-L/14 +0.8 %): profiles/r06_ab_attn_configs.txt.  A/B builds: -DRPO_ATTN_ONE_BARRIER never, -DRPO_ATTN_TWO_PHASE always.
+#ifdef RPO_ATTN_TWO_PHASE
+  const bool two_phase = true;
+#else
+  const bool two_phase = NT == 7 && B * H > rpo_cu_count();
+#endif
+  if constexpr (sizeof(T) == 2) if (two_phase) {
     static rpo_lds_mask_t lds16_ok{0};
 #ifdef RPO_ATTN_DMA                 // (A/B build: K by LDS-DMA into swizzled rows; default: 16-B register loads, padded rows)
     constexpr bool kdma = true;

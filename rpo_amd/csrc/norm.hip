@@ -72,11 +72,10 @@ __global__ __launch_bounds__(64 * RPO_LN_RPB) void img_embed_norm_kernel(float* 
     const float* __restrict__ cls, const float* __restrict__ pos0, const float* __restrict__ prompt,
     const float* __restrict__ g_pre, const float* __restrict__ b_pre, float* x0, int64_t ldx0,
     const float* __restrict__ g1, const float* __restrict__ b1, TY* h, int64_t ldh, int B, int N, int Kp, int d,
-    float eps) {
+    float eps, int row0, int row1) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);
-  const int rows = B * (N + Kp);
-  if (row >= rows) return;
+  const int row = row0 + blockIdx.x * RPO_LN_RPB + (threadIdx.x >> 6);      // rows [row0, row1) of the B * (N + Kp)
+  if (row >= row1) return;
   const int nv4 = d >> 2;
   const bool is_prompt = row >= B * N;
   const bool is_cls = !is_prompt && row % N == 0;
@@ -394,19 +393,27 @@ extern "C" int rpo_img_embed_norm(float* x_pre, int64_t ldx, const float* cls, c
                                   const float* g_pre, const float* b_pre, float* x0, int64_t ldx0, const float* g1,
                                   const float* b1, void* h, int64_t ldh, int h_dtype, int B, int N, int Kp, int d,
                                   float eps, void* stream) {
+  return rpo_img_embed_norm_rows(x_pre, ldx, cls, pos0, img_prompt, g_pre, b_pre, x0, ldx0, g1, b1, h, ldh, h_dtype, B, N, Kp,
+                                 d, eps, 0, B * (N + Kp), stream);
+}
+
+extern "C" int rpo_img_embed_norm_rows(float* x_pre, int64_t ldx, const float* cls, const float* pos0,
+                                       const float* img_prompt, const float* g_pre, const float* b_pre, float* x0,
+                                       int64_t ldx0, const float* g1, const float* b1, void* h, int64_t ldh, int h_dtype,
+                                       int B, int N, int Kp, int d, float eps, int row0, int row1, void* stream) {
   if (!x_pre || !cls || !pos0 || !g_pre || !b_pre || !x0 || !g1 || !b1 || !h || B <= 0 || N <= 0 || Kp < 0 || d <= 0 ||
-      (Kp > 0 && !img_prompt)) return RPO_E_BADARG;
+      row0 < 0 || row1 > B * (N + Kp) || row0 >= row1 || (Kp > 0 && row1 > B * N && !img_prompt)) return RPO_E_BADARG;
   if (d % 4 != 0 || d > 64 * 4 * 4) return RPO_E_SHAPE;
   if (!aligned16(x_pre) || !aligned16(cls) || !aligned16(pos0) || (Kp > 0 && !aligned16(img_prompt)) || !aligned16(g_pre) ||
       !aligned16(b_pre) || !aligned16(x0) || !aligned16(g1) || !aligned16(b1) || ldx % 4 != 0 || ldx0 % 4 != 0 ||
       ldh % 4 != 0 || reinterpret_cast<uintptr_t>(h) % (h_dtype == RPO_F32 ? 16 : 8)) return RPO_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int rows = B * (N + Kp);
+  const int rows = row1 - row0;
   const dim3 grid((rows + RPO_LN_RPB - 1) / RPO_LN_RPB), block(64 * RPO_LN_RPB);
   const int nv = (d / 4 + 63) / 64;
 #define RPO_IEN(TY, NV)                                                                                       \
   hipLaunchKernelGGL((img_embed_norm_kernel<TY, NV>), grid, block, 0, s, x_pre, ldx, cls, pos0, img_prompt, g_pre, \
-                     b_pre, x0, ldx0, g1, b1, static_cast<TY*>(h), ldh, B, N, Kp, d, eps)
+                     b_pre, x0, ldx0, g1, b1, static_cast<TY*>(h), ldh, B, N, Kp, d, eps, row0, row1)
 #define RPO_IEN_NV(TY) do { if (nv <= 2) RPO_IEN(TY, 2); else if (nv == 3) RPO_IEN(TY, 3); else RPO_IEN(TY, 4); } while (0)
   if (h_dtype == RPO_F32) RPO_IEN_NV(float);
   else if (h_dtype == RPO_BF16) RPO_IEN_NV(bf16_t);

@@ -458,6 +458,22 @@ class Engine(CoopEngineMixin):
                     group=cfg.n_patches,                                               # rpo.py:198-202
                     prefetch=self.vis[0].w_in if (self._pf_chains and len(self.vis)) else None)
 
+    def _embed_norm(self, B: int, rows: Optional[tuple] = None) -> None:
+        """CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch, for all token rows or
+        for `rows` = (row0, row1): the frozen rows [0, B*N) depend on the batch alone (the early patch embed forms them for
+        the next batch, RPO.step_async(next_image=...)), the prompt rows [B*N, B*(N+K)) on the prompts."""
+        cfg = self.cfg
+        R = B * (cfg.n_frozen + cfg.K)
+        ops.img_embed_norm(self.x_pre[:R], self.cls, self.pos, self.img_prompt, self.ln_pre[0], self.ln_pre[1], self.x[0][:R],
+                           self.vis[0].ln1_w, self.vis[0].ln1_b, self.h[:R], B, cfg.n_frozen, cfg.K, rows=rows)
+
+    def _patch_embed_early(self, image: torch.Tensor) -> None:
+        """Everything of the image forward that does not depend on the prompts: the patch rows (_patch_embed) and the
+        frozen rows' share of the embedding / ln_pre / first ln_1 launch.  What it writes -- im2col, the patch and CLS rows
+        of x_pre, the frozen rows of x[0] and h -- nothing in a step's backward reads."""
+        self._patch_embed(image)
+        self._embed_norm(image.shape[0], rows=(0, image.shape[0] * self.cfg.n_frozen))
+
     def _image_forward(self, image: torch.Tensor, train: bool, full_last: bool = False, patch_done: bool = False) -> None:
         cfg = self.cfg
         B, N, K, dv, H = image.shape[0], cfg.n_frozen, cfg.K, cfg.d_v, cfg.heads_v
@@ -467,9 +483,9 @@ class Engine(CoopEngineMixin):
         if not patch_done:                      # (patch_done: _patch_embed(image) has already been enqueued for this batch)
             self._patch_embed(image)
         h, att, g = self.h[:R], self.att[:R], self.g[:R]
-        # CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch
-        ops.img_embed_norm(x_pre, self.cls, self.pos, self.img_prompt, self.ln_pre[0], self.ln_pre[1], self.x[0][:R],
-                           self.vis[0].ln1_w, self.vis[0].ln1_b, h, B, N, K)
+        # CLS / prompt rows (rpo.py:201-204), ln_pre (:206) and the first block's ln_1 in one launch; behind an early
+        # patch embed only the prompt rows are left
+        self._embed_norm(B, rows=(Rf, R) if (patch_done and K > 0) else None)
         fold = self.fold_ln
         # Row units of the whole-stream GEMMs: one image = N frozen + K prompt rows.  With them c_fc tiles by image
         # (saved pre-activations spread over all workgroups) and out-proj / c_proj run as one round of 224x96 tiles,

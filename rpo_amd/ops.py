@@ -304,12 +304,14 @@ def im2col_patches(img: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Te
 
 
 def img_embed_norm(x_pre, cls, pos0, img_prompt, g_pre, b_pre, x0, g1, b1, h, B: int, N: int, Kp: int,
-                   eps: float = LN_EPS):
-    """img_assemble + ln_pre (-> x0) + the first block's ln_1 (-> h) in one launch."""
-    check(_lib.load().rpo_img_embed_norm(x_pre.data_ptr(), _ld(x_pre), cls.data_ptr(), pos0.data_ptr(), _p(img_prompt),
-                                         g_pre.data_ptr(), b_pre.data_ptr(), x0.data_ptr(), _ld(x0), g1.data_ptr(),
-                                         b1.data_ptr(), h.data_ptr(), _ld(h), dtype_code(h.dtype), B, N, Kp,
-                                         x_pre.shape[1], eps, _stream()), "rpo_img_embed_norm")
+                   eps: float = LN_EPS, rows: Optional[tuple] = None):
+    """img_assemble + ln_pre (-> x0) + the first block's ln_1 (-> h) in one launch.  rows = (row0, row1): those token rows
+    only (rpo_img_embed_norm_rows: the frozen rows [0, B*N) do not depend on the prompts)."""
+    r0, r1 = (0, B * (N + Kp)) if rows is None else rows
+    check(_lib.load().rpo_img_embed_norm_rows(x_pre.data_ptr(), _ld(x_pre), cls.data_ptr(), pos0.data_ptr(), _p(img_prompt),
+                                              g_pre.data_ptr(), b_pre.data_ptr(), x0.data_ptr(), _ld(x0), g1.data_ptr(),
+                                              b1.data_ptr(), h.data_ptr(), _ld(h), dtype_code(h.dtype), B, N, Kp,
+                                              x_pre.shape[1], eps, r0, r1, _stream()), "rpo_img_embed_norm_rows")
     return h
 
 

@@ -286,7 +286,7 @@ class RPO:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                eng._patch_embed(src)
+                eng._patch_embed_early(src)
             self._g_patch[src.data_ptr()] = (g, src)          # (keeps the buffer alive as long as its graph)
             torch.cuda.synchronize()
         else:
@@ -325,15 +325,17 @@ class RPO:
                 self.sync.all_reduce_sum(self.engine.g_text_flat)
             if self._early_text:
                 self._run_tail("text")              # SGD on the text prompts, then the NEXT step's text forward
-                self._ev_text_bwd.record(side)
+            self._ev_text_bwd.record(side)
+            if g_patch is not None:
+                # the NEXT batch's patch rows, behind the text backward and IN FRONT of the early text forward: the next image
+                # forward waits for them, and behind a 0.45 ms text forward that wait serialised the two towers (first
+                # version: batch 4 1.82 vs 1.47 ms, profiles/r06_bench_batchsweep.json of that tree)
+                g_patch.replay()
+                self._ev_patch.record(side)
+            if self._early_text:
                 self._g_text_fwd.replay()
                 self._ev_text_fwd.record(side)
                 self._text_fwd_for = self.engine.params_version + 1     # (step_async bumps the version after the tail)
-            else:
-                self._ev_text_bwd.record(side)
-            if g_patch is not None:                 # the NEXT batch's patch rows, behind the text chain
-                g_patch.replay()
-                self._ev_patch.record(side)
         if self._bwd_parts > 1:
             for st, ev, g in zip(self._part_streams, self._ev_parts, self._g_img_bwd_parts[1:]):
                 st.wait_event(self._ev_head)

@@ -60,7 +60,7 @@ def test_library_loads_and_probe_layouts():
     """The fragment layouts every MFMA kernel assumes, checked on the device with an
     ASYMMETRIC operand pair (a transposed C/D map cannot pass)."""
     o = ops()
-    assert o.version() == 7
+    assert o.version() == 8
     for which, kdim in ((0, 16), (1, 2)):
         g = torch.Generator().manual_seed(which)
         a = torch.randint(-4, 5, (32, kdim), generator=g).float()

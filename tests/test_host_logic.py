@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"librpo_hip.so does not export {n}"
         assert n in _lib.SIGNATURES, f"no ctypes signature for {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.load().rpo_version() == 7
+    assert _lib.load().rpo_version() == 8
     assert b"shape" in _lib.load().rpo_error_string(-2)
 
 

@@ -4,7 +4,7 @@
 # Prints ms/step and the in-step kernel times (roofline.kernels) of every run.
 export TMPDIR=/tmp
 extra=$1; shift
-for i in 1 2 3; do
+for i in $(seq 1 ${ROUNDS:-3}); do
  for arm in "$@"; do
   name=${arm%%:*}; envs=""; [ "$arm" != "$name" ] && envs=${arm#*:}
   ( if [ $name != default ]; then export RPO_HIP_LIB=$PWD/rpo_amd/build/ab/librpo_$name.so; fi

@@ -62,5 +62,26 @@ keep bench_text_attn.txt 100 python tools/bench_text_attn.py
 [ -z "${QUICK:-}" ] && [ -x tools/build/ubench_dma ] && keep ubench_dma.txt 100 tools/build/ubench_dma
 # the image tower as P part-batches on P streams (round 3: does de-phasing the one-round kernels help?)
 [ -z "${QUICK:-}" ] && keep half_batch_probe.txt 200 python tools/probe_half_batch.py 32 1 2 4
+# ---- round 6 ----------------------------------------------------------------------------------------------------------
+# the reference's ImageNet-size class set (configs/trainers/RPO/imagenet_k24_ep15.yaml): bench line + kernel trace
+timeout 600 python bench.py --n-cls 1000 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_ncls1000.json 2>> $O/bench.err
+timeout 300 python bench.py --n-cls 100 --steps 30 --warmup 5 --no-cpu-baseline --no-precision --no-f16-sibling > $O/bench_ncls100.json 2>> $O/bench.err
+timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $O/trace1000 -o t -- python bench.py --n-cls 1000 --steps 6 --warmup 2 --no-cpu-baseline --no-precision --no-f16-sibling > $O/bench_traced1000.json 2> $O/trace1000.err
+keep trace_ncls1000.txt 60 python tools/prof_stats.py $(find $O/trace1000 -name "*_results.db" | head -1) 30
+rm -rf $O/trace1000
+# N > 1 readiness on one GPU: a one-rank RCCL communicator, three collective schedules, bit-identical (bench.py --dry-scale)
+timeout 300 python bench.py --dry-scale 2> $O/dry_scale.err | grep dry_scale > $O/dry_scale.json
+# attention forward: the shipped kernel against its A/B builds (tools/build_variant.sh, SRC=attn_image), kernel alone ...
+if ls rpo_amd/build/ab/librpo_*.so > /dev/null 2>&1; then
+  : > $O/attn_variants.txt
+  for v in default onebar oldattn dma lazy tpi2; do
+    if [ $v = default ]; then lib=""; else lib=$PWD/rpo_amd/build/ab/librpo_$v.so; [ -f $lib ] || continue; fi
+    echo "== $v" >> $O/attn_variants.txt
+    RPO_HIP_LIB=$lib timeout 120 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids >> $O/attn_variants.txt
+  done
+  # ... and in the step, with the round-5 path (round-5 attention loop, no early patch embed) as one of the arms
+  keep ab_round5_path_vs_round6.txt 900 bash tools/ab_libs.sh "" default oldattn:RPO_EARLY_PATCH=0 default:RPO_EARLY_PATCH=0 default:RPO_EARLY_PATCH=0,RPO_ONE_GRAPH=1
+fi
+BENCH_CFGS=2,3,6,9 keep bench_gemm_t1k.txt 300 python tools/bench_gemm.py --only "t1k_*"
 ls $O
 if [ -n "$FAILED" ]; then echo "collect_profiles: FAILED:$FAILED (outputs under $O/failed/, nothing of them will be summarised)" >&2; exit 1; fi

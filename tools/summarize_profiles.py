@@ -170,13 +170,15 @@ if f:
                 if ga > 0 and busy > 0:
                     fo.write(f"{nm:72s} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / busy:6.3f} {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (ga / 8 * 1024):6.3f}\n")
 for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_f16.json", "bench_eval.json", "bench_input_pipeline.json",
-           "bench_batchsweep.json", "bench_2rank_selflaunch.json", "bench_coop.json", "bench_cocoop.json"):
+           "bench_batchsweep.json", "bench_2rank_selflaunch.json", "bench_coop.json", "bench_cocoop.json",
+           "bench_ncls1000.json", "bench_ncls100.json", "dry_scale.json"):
     src = os.path.join(raw, fn)
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, os.path.join(out, f"{tag}_{fn}"))
 bad = False
 for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt", "cu_mask_probe.txt",
-           "attn_timeline.txt", "attn_bwd_timeline.txt", "half_batch_probe.txt", "gemm_ws_timeline.txt", "bench_gemm_ws.txt", "bench_text_attn.txt"):
+           "attn_timeline.txt", "attn_bwd_timeline.txt", "half_batch_probe.txt", "gemm_ws_timeline.txt", "bench_gemm_ws.txt", "bench_text_attn.txt",
+           "trace_ncls1000.txt", "attn_variants.txt", "ab_round5_path_vs_round6.txt", "bench_gemm_t1k.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
