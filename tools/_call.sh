@@ -1,6 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/c13; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -m gpu -q -k "early_patch or early_text or graph_replay or golden or attn or embed or patch" 2>&1 | tail -4 > $O/pytest_sel.txt
-ROUNDS=3 bash tools/ab_libs.sh "" default default:RPO_EARLY_PATCH=0 > $O/ab_early_embed.txt 2>&1
-ROUNDS=2 bash tools/ab_libs.sh "--batch 4" default default:RPO_EARLY_PATCH=0 >> $O/ab_early_embed.txt 2>&1
-cat $O/pytest_sel.txt $O/ab_early_embed.txt
+mkdir -p gpurun_out/c14
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/c14/pytest.txt
+RPO_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -m gpu -q -k "joint_backward or mlp_fused or split_row or persistent_backward or pair or chain" 2>&1 | tail -3 > gpurun_out/c14/pytest_exp.txt
+timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 > gpurun_out/c14/smoke.txt
+QUICK=1 bash tools/collect_profiles.sh > gpurun_out/c14/collect.log 2>&1
+echo "collect rc=$?" >> gpurun_out/c14/collect.log
+cat gpurun_out/c14/pytest.txt gpurun_out/c14/pytest_exp.txt gpurun_out/c14/smoke.txt; tail -3 gpurun_out/c14/collect.log

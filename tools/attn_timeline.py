@@ -22,8 +22,10 @@ H, N, Kp, d = 12, 197, 24, 768
 # first 128 K rows committed, 3 = barrier A passed, 4 = key tiles 0 .. 3 done, 5 = rest of K committed + barrier B passed,
 # 6 = remaining key tiles + partial tile + stores issued.  (The one-barrier kernel -- f32 mode, -DRPO_ATTN_ONE_BARRIER --
 # has no stamps 4 / 5: absent stamps are skipped.)
-names = ["start", "q + V landed, V^T built", "K rows [0,128) committed", "barrier A passed", "key tiles 0-3 (phase A)",
-         "rest of K committed, barrier B passed", "remaining key tiles + stores issued", "stores drained"]
+names2 = ["start", "q + V landed, V^T built", "K rows [0,128) committed", "barrier A passed", "key tiles 0-3 (phase A)",
+          "rest of K committed, barrier B passed", "remaining key tiles + stores issued", "stores drained"]
+names1 = ["start", "K staged (issued+written)", "V^T built", "barrier passed", "-", "-",
+          "key loop (S^T, softmax, P.V) + stores issued", "stores drained"]
 for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
     qkv = torch.randn(B * (N + Kp), 3 * d, device=dev).to(torch.bfloat16)
     out = torch.empty(B * (N + Kp), d, dtype=torch.bfloat16, device=dev)
@@ -42,5 +44,6 @@ for B in [int(a) for a in sys.argv[1:]] or [16, 32]:
         r = t[b]
         if r[0] == 0: continue
         have = [i for i in range(8) if r[i] != 0]
+        names = names2 if (r[4] != 0 and r[5] != 0) else names1       # which kernel the launcher took for this shape
         assert have[0] == 0 and have[-1] == 7 and all(r[a] <= r[b] for a, b in zip(have, have[1:])), r
         print(f"wg {b*97}: " + " | ".join(f"{names[i]} +{int(r[i]-r[j])}" for j, i in zip(have, have[1:])) + f" | total {int(r[7]-r[0])}")

@@ -74,7 +74,7 @@ timeout 300 python bench.py --dry-scale 2> $O/dry_scale.err | grep dry_scale > $
 # attention forward: the shipped kernel against its A/B builds (tools/build_variant.sh, SRC=attn_image), kernel alone ...
 if ls rpo_amd/build/ab/librpo_*.so > /dev/null 2>&1; then
   : > $O/attn_variants.txt
-  for v in default onebar oldattn dma lazy tpi2; do
+  for v in default twophase onebar oldattn dma lazy tpi2; do
     if [ $v = default ]; then lib=""; else lib=$PWD/rpo_amd/build/ab/librpo_$v.so; [ -f $lib ] || continue; fi
     echo "== $v" >> $O/attn_variants.txt
     RPO_HIP_LIB=$lib timeout 120 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids >> $O/attn_variants.txt
