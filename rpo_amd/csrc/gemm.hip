@@ -257,20 +257,29 @@ __device__ __forceinline__ void aux_store4(const GemmParams& p, int64_t off, con
 
 // Epilogues that read a second [M, N] operand (residual / saved pre-activation) can fetch it BEFORE the main loop when
 // the row-major pass of a thread is a single group of 4 rows (64-row tiles: 4 float4 = 16 VGPRs): the HBM round trip
-// then overlaps the k-loop instead of sitting in the epilogue.
+// then overlaps the k-loop instead of sitting in the epilogue.  Round 6: also the 8 rows of the 128x128 tiles (32 VGPRs
+// of the 128 a wave has at two workgroups per CU; the kernel used 76) -- the 24 000-row text tower of the 1000-class
+// workload runs its residual / d QuickGELU GEMMs on them with 8-tile k-loops (K = 512), where two exposed round trips
+// per tile were a third of the tile's life (-DRPO_EPI_PRE4_ONLY: the round-5 behaviour).
 template <int EPI, typename CF>
 struct EpiPre {
-  static constexpr int CPR = CF::BN / 4, RPP = CF::THREADS / CPR;
-  static constexpr bool value = !CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_QGELU_BWD) && CF::BM / RPP == 4;
+  static constexpr int CPR = CF::BN / 4, RPP = CF::THREADS / CPR, ROWS = CF::BM / RPP;
+#ifdef RPO_EPI_PRE4_ONLY
+  static constexpr bool rows_ok = ROWS == 4;
+#else
+  static constexpr bool rows_ok = ROWS == 4 || ROWS == 8;
+#endif
+  static constexpr bool value = !CF::PRECONV_EPI && (EPI == RPO_EPI_BIAS_RESID || EPI == RPO_EPI_QGELU_BWD) && rows_ok;
+  static constexpr int N = value ? ROWS : 4;
 };
 template <int EPI, typename CF, typename TA>
-__device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0, float4 (&pre)[4]) {
+__device__ __forceinline__ void epi_preload(const GemmParams& p, int m0, int n0, float4 (&pre)[EpiPre<EPI, CF>::N]) {
   constexpr int CPR = EpiPre<EPI, CF>::CPR, RPP = EpiPre<EPI, CF>::RPP;
   const int tid = threadIdx.x;
   const int cc = tid % CPR, r0 = tid / CPR;
   const int n = n0 + cc * 4;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < EpiPre<EPI, CF>::N; ++u) {
     const int m = m0 + u * RPP + r0;
     pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.N && m < p.M) {
@@ -435,6 +444,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     TOut* cbase = reinterpret_cast<TOut*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
     auto row_major_pass = [&](auto save_u_tag) {        // (see convert_and_stage above for the tag)
       constexpr bool SAVE_U = decltype(save_u_tag)::value;
+      constexpr int PASS_UNROLL = EpiPre<EPI, CF>::value ? EpiPre<EPI, CF>::N / UNR : 1;   // (static indices into pre[])
+  #pragma unroll(PASS_UNROLL)
       for (int pass0 = 0; pass0 < BM / RPP; pass0 += UNR) {
         float4 ex[UNR];
         int64_t orow[UNR];
@@ -447,7 +458,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           orow[u] = mc;
           ex[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (EpiPre<EPI, CF>::value) {            // loaded before the main loop (see the kernel)
-            ex[u] = pre[u];
+            ex[u] = pre[pass0 + u];
           } else if (EPI == RPO_EPI_PATCH) {
             const int img = mc / p.group;
             orow[u] = (int64_t)mc + img + 1;
@@ -585,7 +596,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmParams& p, char* smem, co
     const int n = n0 + (tid % (CF::BN / 4)) * 4;
     if (n < p.N) pre_b = *reinterpret_cast<const float4*>(p.bias + n);
   }
-  float4 pre[4];
+  float4 pre[EpiPre<EPI, CF>::N];
   if constexpr (EpiPre<EPI, CF>::value) {
     epi_preload<EPI, CF, TIn>(p, m0, n0, pre);     // plain loads: they count in vmcnt like the DMA, issued in order before the
                                               // in-loop DMA, so the counted waits below stay valid (conservative)

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restric
 // per image: loss_b = logsumexp - logit[label]; dl[b,c] = (softmax - onehot) * gmul
 __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ logits,
                                                       const int64_t* __restrict__ label, float* dl,
-                                                      float* loss_b, int C, float gmul) {
+                                                      float* loss_b, int C, float gmul, float* dlT, int B) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* z = logits + (int64_t)b * C;
@@ -262,8 +262,11 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ 
   // ... and so do this image's dl weights, hence both prompt gradients: rpo_sgd_step_guarded / check_finite then see the
   // bad label instead of applying a finite-looking (softmax without its one-hot term) update
   const float poison = lb_ok ? 0.0f : __builtin_nanf("");
-  for (int c = threadIdx.x; c < C; c += 256)
-    dl[(int64_t)b * C + c] = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul + poison;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float w = (expf(z[c] - m) * inv - (c == lb ? 1.0f : 0.0f)) * gmul + poison;
+    dl[(int64_t)b * C + c] = w;
+    if (dlT != nullptr) dlT[(int64_t)c * B + b] = w;               // (the MFMA backward of the image side reads it by class)
+  }
   if (threadIdx.x == 0) loss_b[b] = lb_ok ? (m + logf(s)) - z[lb] : __builtin_nanf("");
 }
 
@@ -373,6 +376,221 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         if (act_dtype == RPO_BF16) reinterpret_cast<uint16_t*>(da)[(int64_t)row * e + idx] = (uint16_t)(pack2<bf16_t>(g, 0.f) & 0xffffu);
         else reinterpret_cast<uint16_t*>(da)[(int64_t)row * e + idx] = (uint16_t)(pack2<f16_t>(g, 0.f) & 0xffffu);
       }
+    }
+  }
+}
+
+// ---- head at large class counts (C > 128: SUN397, ImageNet's 1000) -------------------------------------------------------
+// The kernels above give every (class, image) pair / every feature row its own block, each re-reading the rows of the other
+// side: 3 GB of L2 reads per launch at 1000 classes x 32 images x K = 24 (243 + 337 us).  Here the pairings are what they
+// are -- K small GEMMs, one per prompt index i -- on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+// accumulation in a fixed order), every feature element read once per launch:
+//   head_pairs:   P[i][b][c] = <x_bi, t_ci> / (|x_bi| |t_ci|); one wave per (32-class tile, i); leaves 1/|x|, 1/|t| in ni / nt
+//   head_sum:     logits[b][c] = (scale / K) sum_i P[i][b][c]                           (fixed order)
+//   head_ce_kernel (above), also writing dl transposed
+//   head_rowdots: s_t[c,i] = sum_b dl[b,c] P[i][b][c],  s_x[b,i] = sum_c dl[b,c] P[i][b][c]   (= <h, dh> of the row)
+//   head_bwd_text / head_bwd_img:  df = (dh - h <h, dh>) / |f|,  dh = sum_o dl(g, o) other_hat[o, i, :]  as
+//                 D[class][e] = sum_b (dl[b,c] / |x_bi|) x_bi[e]   resp.   D[b][e] = sum_c (dl[b,c] / |t_ci|) t_ci[e]
+// Lane maps of the MFMA (probe_kernel below): operand values come from (row l31, k = half) of A and B; acc[r] is
+// D[(r & 3) + 8 (r >> 2) + 4 half][l31].
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__global__ __launch_bounds__(64) void head_pairs_kernel(const float* __restrict__ f_img, const float* __restrict__ f_txt,
+                                                        float* ni, float* nt, float* part, int B, int C, int K, int e) {
+  __shared__ float s_ix[32];
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int c0 = blockIdx.x * 32, i = blockIdx.y;
+  const int c = min(c0 + l31, C - 1);
+  const float* t = f_txt + ((int64_t)c * K + i) * e + 4 * half;    // this lane's k's of an 8-wide step: 4 half .. 4 half + 3
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int b = min(b0 + l31, B - 1);
+    const float* x = f_img + ((int64_t)b * K + i) * e + 4 * half;
+    f32x16_t d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    float st = 0.f, sx = 0.f;
+    for (int q0 = 0; q0 < e; q0 += 32) {                            // (e % 32 == 0: the launcher) 8 loads in flight, 16 MFMAs
+      float4 xv[4], tv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[j] = *reinterpret_cast<const float4*>(x + q0 + 8 * j);
+        tv[j] = *reinterpret_cast<const float4*>(t + q0 + 8 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].x, tv[j].x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].y, tv[j].y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].z, tv[j].z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[j].w, tv[j].w, d, 0, 0, 0);
+        sx = fmaf(xv[j].x, xv[j].x, sx); sx = fmaf(xv[j].y, xv[j].y, sx); sx = fmaf(xv[j].z, xv[j].z, sx); sx = fmaf(xv[j].w, xv[j].w, sx);
+        st = fmaf(tv[j].x, tv[j].x, st); st = fmaf(tv[j].y, tv[j].y, st); st = fmaf(tv[j].z, tv[j].z, st); st = fmaf(tv[j].w, tv[j].w, st);
+      }
+    }
+    sx += __shfl_xor(sx, 32);                                       // the two halves of the row
+    st += __shfl_xor(st, 32);
+    const float ix = 1.0f / sqrtf(sx), it = 1.0f / sqrtf(st);
+    __syncthreads();                                                // (the previous image tile's readers are done)
+    if (half == 0) {
+      s_ix[l31] = ix;
+      if (blockIdx.x == 0 && b0 + l31 < B) ni[(int64_t)b * K + i] = ix;
+      if (b0 == 0 && c0 + l31 < C) nt[(int64_t)c * K + i] = it;
+    }
+    __syncthreads();
+    if (c0 + l31 < C) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bb = b0 + mfma_row(r, half);
+        if (bb < B) part[((int64_t)i * B + bb) * C + c] = d[r] * s_ix[mfma_row(r, half)] * it;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ part, float* logits, int BC, int K, float mul) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BC) return;
+  float s = 0.f;
+  for (int i = 0; i < K; ++i) s += part[(int64_t)i * BC + idx];
+  logits[idx] = s * mul;
+}
+
+// blocks [0, K * ceil(C / 256)): s_t, one thread per (i, c); then B * K blocks: s_x, one block per (b, i); block 0 also the
+// mean loss
+__global__ __launch_bounds__(256) void head_rowdots_kernel(const float* __restrict__ dl, const float* __restrict__ part,
+                                                           float* s_t, float* s_x, int B, int C, int K,
+                                                           const float* loss_b, float* loss) {
+  __shared__ float red[4];
+  const int ct = (C + 255) / 256;
+  if (loss != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {    // mean CE over the batch, fixed summation order
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += loss_b[b];
+    *loss = s / (float)B;
+  }
+  if ((int)blockIdx.x < K * ct) {
+    const int i = blockIdx.x / ct, c = (blockIdx.x - i * ct) * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dl[(int64_t)b * C + c], part[((int64_t)i * B + b) * C + c], s);
+    s_t[(int64_t)c * K + i] = s;
+  } else {
+    const int row = blockIdx.x - K * ct, b = row / K, i = row - b * K;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s = fmaf(dl[(int64_t)b * C + c], part[((int64_t)i * B + b) * C + c], s);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) s_x[row] = s;
+  }
+}
+
+__device__ __forceinline__ void head_store(float* df, void* da, int act_dtype, int64_t off, float g) {
+  df[off] = g;
+  if (da != nullptr) {                       // the act-dtype copy the dX GEMM of the projection reads (RNE, as rpo_convert)
+    if (act_dtype == RPO_BF16) reinterpret_cast<uint16_t*>(da)[off] = (uint16_t)(pack2<bf16_t>(g, 0.f) & 0xffffu);
+    else reinterpret_cast<uint16_t*>(da)[off] = (uint16_t)(pack2<f16_t>(g, 0.f) & 0xffffu);
+  }
+}
+
+// d text_f: one wave per (32-class tile, i, group of e-tiles); D[class][e] over the image pairs (2 kk, 2 kk + 1)
+__global__ __launch_bounds__(64) void head_bwd_text_kernel(const float* __restrict__ dl, const float* __restrict__ f_img,
+                                                           const float* __restrict__ ni, const float* __restrict__ f_txt,
+                                                           const float* __restrict__ nt, const float* __restrict__ s_t,
+                                                           float* d_text_f, void* d_text_a, int act_dtype, int B, int C,
+                                                           int K, int e, int etiles_per_block) {
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int c0 = blockIdx.x * 32, i = blockIdx.y;
+  const int c = min(c0 + l31, C - 1);
+  float itv[16], cf[16];                                            // per accumulator row: 1 / |t|, <h, dh> / |t|^2
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int cn = min(c0 + mfma_row(r, half), C - 1);
+    const float it = nt[(int64_t)cn * K + i];
+    itv[r] = it; cf[r] = it * it * s_t[(int64_t)cn * K + i];
+  }
+  const int npair = (B + 1) >> 1;
+  // weights of 16 image pairs at a time (pairs past B: weight 0); one chunk (B <= 32): formed once for all e-tiles
+  auto weights = [&](int kk0, float (&a)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int b = 2 * (kk0 + j) + half, bc = min(b, B - 1);
+      a[j] = dl[(int64_t)bc * C + c] * ni[(int64_t)bc * K + i];
+      if (b >= B) a[j] = 0.f;
+    }
+  };
+  float a0[16];
+  weights(0, a0);
+  for (int et = blockIdx.z * etiles_per_block; et < min((int)(blockIdx.z + 1) * etiles_per_block, e >> 5); ++et) {
+    const int col = et * 32 + l31;
+    f32x16_t d;
+    float tq[16], xv[16];                                           // the rows' own values (epilogue), requested up front
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xv[j] = f_img[((int64_t)min(2 * j + half, B - 1) * K + i) * e + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      d[r] = 0.f;
+      tq[r] = f_txt[((int64_t)min(c0 + mfma_row(r, half), C - 1) * K + i) * e + col];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], xv[j], d, 0, 0, 0);
+    for (int kk0 = 16; kk0 < npair; kk0 += 16) {                    // more than 32 images
+      float a[16];
+      weights(kk0, a);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xv[j] = f_img[((int64_t)min(2 * (kk0 + j) + half, B - 1) * K + i) * e + col];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], xv[j], d, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cn = c0 + mfma_row(r, half);
+      if (cn < C) {
+        const int64_t off = ((int64_t)cn * K + i) * e + col;
+        head_store(d_text_f, d_text_a, act_dtype, off, d[r] * itv[r] - tq[r] * cf[r]);
+      }
+    }
+  }
+}
+
+// d img_f: one workgroup per (i, e-tile, 32-image tile); D[image][e] over the class pairs, which the 8 waves split (wave w:
+// pairs w, w + 8, ... in batches of 8: 24 loads in flight per wave, ~3 waves per SIMD at 1000 classes); the eight partial
+// tiles are summed through LDS in wave order.  dlT = dl transposed [C][B].
+constexpr int HEAD_IMG_WAVES = 8;
+__global__ __launch_bounds__(64 * HEAD_IMG_WAVES) void head_bwd_img_kernel(
+    const float* __restrict__ dlT, const float* __restrict__ f_img, const float* __restrict__ ni,
+    const float* __restrict__ f_txt, const float* __restrict__ nt, const float* __restrict__ s_x, float* d_img_f,
+    void* d_img_a, int act_dtype, int B, int C, int K, int e) {
+  __shared__ float s_part[HEAD_IMG_WAVES][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int i = blockIdx.x, col = blockIdx.y * 32 + l31, b0 = blockIdx.z * 32;
+  const int b = min(b0 + l31, B - 1);
+  f32x16_t d;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[r] = 0.f;
+  const int npair = (C + 1) >> 1;
+  for (int kk0 = wave; kk0 < npair; kk0 += 8 * HEAD_IMG_WAVES) {   // (pairs past C: weight 0)
+    float a[8], tv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = 2 * (kk0 + j * HEAD_IMG_WAVES) + half, ccl = min(cc, C - 1);
+      a[j] = dlT[(int64_t)ccl * B + b] * nt[(int64_t)ccl * K + i];
+      if (cc >= C) a[j] = 0.f;
+      tv[j] = f_txt[((int64_t)ccl * K + i) * e + col];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], tv[j], d, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_part[wave][r][lane] = d[r];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16 / HEAD_IMG_WAVES; ++rr) {
+    const int r = wave + HEAD_IMG_WAVES * rr;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < HEAD_IMG_WAVES; ++w) v += s_part[w][r][lane];
+    const int bn = b0 + mfma_row(r, half);
+    if (bn < B) {
+      const float ix = ni[(int64_t)bn * K + i];
+      const int64_t off = ((int64_t)bn * K + i) * e + col;
+      head_store(d_img_f, d_img_a, act_dtype, off, v * ix - f_img[off] * (ix * ix * s_x[(int64_t)bn * K + i]));
     }
   }
 }
@@ -554,6 +772,35 @@ extern "C" int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, con
   float* lb = dl + (int64_t)B * C;
   const float gmul = scale_exp / ((float)K * (float)B);
   const float mul = scale_exp / (float)K;
+  // Large class sets on the fp32 matrix pipe (kernels above).  Their scratch -- P [K][B][C], dl transposed, s_t, s_x -- lies
+  // in the workspace behind the arrays of the small-set path; sets whose scratch does not fit keep the kernels above.
+  float* part = lb + B;
+  float* dlT = part + (int64_t)K * B * C;
+  float* s_t = dlT + (int64_t)B * C;
+  float* s_x = s_t + (int64_t)C * K;
+#ifdef RPO_HEAD_NO_MFMA
+  const bool mfma_head = false;
+#else
+  const bool mfma_head = C > 128 && e % 32 == 0 && aligned16(img_f) && aligned16(text_f) &&
+                         (s_x + (int64_t)B * K) - ws <= rpo_head_workspace_floats(B, C, K, e) && (int64_t)B * C < (1ll << 31);
+#endif
+  if (mfma_head) {
+    hipLaunchKernelGGL(head_pairs_kernel, dim3((C + 31) / 32, K), dim3(64), 0, s, img_f, text_f, ni, nt, part, B, C, K, e);
+    hipLaunchKernelGGL(head_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, logits, B * C, K, mul);
+    if (!label) return rpo_launch_status();
+    hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul, dlT, B);
+    hipLaunchKernelGGL(head_rowdots_kernel, dim3(K * ((C + 255) / 256) + B * K), dim3(256), 0, s, dl, part, s_t, s_x, B, C, K,
+                       lb, loss);
+#ifndef RPO_HEAD_TEXT_EZ
+#define RPO_HEAD_TEXT_EZ 4
+#endif
+    const int etiles = e / 32, ez = etiles >= RPO_HEAD_TEXT_EZ ? RPO_HEAD_TEXT_EZ : 1;
+    hipLaunchKernelGGL(head_bwd_text_kernel, dim3((C + 31) / 32, K, ez), dim3(64), 0, s, dl, img_f, ni, text_f, nt, s_t,
+                       d_text_f, d_text_act, act_dtype, B, C, K, e, (etiles + ez - 1) / ez);
+    hipLaunchKernelGGL(head_bwd_img_kernel, dim3(K, etiles, (B + 31) / 32), dim3(64 * HEAD_IMG_WAVES), 0, s, dlT, img_f, ni, text_f, nt, s_x,
+                       d_img_f, d_img_act, act_dtype, B, C, K, e);
+    return rpo_launch_status();
+  }
   if (e % 256 == 0 && aligned16(img_f) && aligned16(text_f))
     hipLaunchKernelGGL(head_logits_kernel<true>, dim3(C, B), dim3(256), 0, s, img_f, text_f, ni, nt, logits, C, K, e, mul);
   else
@@ -569,7 +816,7 @@ extern "C" int rpo_head_fwd_bwd_act(const float* img_f, const float* text_f, con
     return rpo_launch_status();
   }
   if ((size_t)nmax * sizeof(float) > 64 * 1024) return RPO_E_SHAPE;
-  hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul);
+  hipLaunchKernelGGL(head_ce_kernel, dim3(B), dim3(256), 0, s, logits, label, dl, lb, C, gmul, static_cast<float*>(nullptr), 0);
   hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(B * K + C * K), dim3(256), (size_t)nmax * sizeof(float), s, dl, img_f,
                      ni, text_f, nt, d_img_f, d_text_f, B, C, K, e, lb, loss, logits, label, gmul, d_img_act, d_text_act, act_dtype);
   return rpo_launch_status();

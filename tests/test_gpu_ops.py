@@ -952,8 +952,10 @@ def test_text_attn_fwd_bwd(mode, lens, Kr):
 
 @pytest.mark.parametrize("B,C,K,e", [(4, 19, 24, 512), (32, 19, 24, 512), (100, 37, 16, 512), (5, 128, 8, 768),
                                      (3, 300, 4, 768), (1, 2, 1, 64), (7, 3, 5, 100),
-                                     # the three-launch path at the reference's ImageNet size and just past the fused path's 128
-                                     (32, 1000, 24, 512), (2, 129, 1, 768)])
+                                     # the matrix-pipe path (C > 128) at the reference's ImageNet size and just past the fused path's 128
+                                     (32, 1000, 24, 512), (2, 129, 1, 768),
+                                     # ... whose kernels tile images and classes by 32: ragged tiles on both sides, odd pair counts
+                                     (40, 397, 24, 512), (33, 131, 3, 64)])
 def test_head_fwd_bwd(B, C, K, e):
     o = ops()
     i_f, t_f = rnd((B, K, e), 31), rnd((C, K, e), 32)
