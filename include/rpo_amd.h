@@ -316,7 +316,9 @@ int rpo_metanet_bwd(const float* d_bias, const float* f_norm, const float* hidde
  * NaN (F.cross_entropy raises; a kernel cannot) and reads nothing out of bounds.
  * workspace: fp32, at least rpo_head_workspace_floats(B, C, K, e) elements; no initialisation needed.
  * Two launches per training step for class sets up to 128 (logits + norms over B*C blocks; backward with the softmax
- * recomputed per block), three above; e <= 1024. */
+ * recomputed per block).  Above 128 classes (e a multiple of 32, 16-byte aligned features) the K pairings run as K small
+ * GEMMs on the fp32 matrix pipe, six launches, every feature element read once; their scratch lies inside the same
+ * workspace.  Fixed summation orders in both; e <= 1024. */
 int64_t rpo_head_workspace_floats(int B, int C, int K, int e);
 int rpo_head_fwd_bwd(const float* img_f, const float* text_f, const int64_t* label, float scale_exp,
                      float* logits, float* loss, float* d_img_f, float* d_text_f,

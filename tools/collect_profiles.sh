@@ -83,5 +83,11 @@ if ls rpo_amd/build/ab/librpo_*.so > /dev/null 2>&1; then
   keep ab_round5_path_vs_round6.txt 900 bash tools/ab_libs.sh "" default oldattn:RPO_EARLY_PATCH=0 default:RPO_EARLY_PATCH=0 default:RPO_EARLY_PATCH=0,RPO_ONE_GRAPH=1
 fi
 BENCH_CFGS=2,3,6,9 keep bench_gemm_t1k.txt 300 python tools/bench_gemm.py --only "t1k_*"
+# the head (cosine logits + cross-entropy, forward + backward) alone at 19 .. 1000 classes: the matrix-pipe kernels for class
+# sets above 128 against the -DRPO_HEAD_NO_MFMA build (SRC=misc tools/build_variant.sh oldhead -DRPO_HEAD_NO_MFMA), alone
+# and in the 1000-class step
+{ echo "== default"; timeout 120 python tools/bench_head.py 2>&1 | grep -v amdgpu.ids
+  if [ -f rpo_amd/build/ab/librpo_oldhead.so ]; then echo "== oldhead (-DRPO_HEAD_NO_MFMA)"; RPO_HIP_LIB=$PWD/rpo_amd/build/ab/librpo_oldhead.so timeout 120 python tools/bench_head.py 2>&1 | grep -v amdgpu.ids; fi; } > $O/bench_head.txt
+[ -f rpo_amd/build/ab/librpo_oldhead.so ] && ROUNDS=3 keep ab_head_ncls1000.txt 600 bash tools/ab_libs.sh "--n-cls 1000 --no-f16-sibling" default oldhead
 ls $O
 if [ -n "$FAILED" ]; then echo "collect_profiles: FAILED:$FAILED (outputs under $O/failed/, nothing of them will be summarised)" >&2; exit 1; fi

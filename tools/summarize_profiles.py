@@ -178,7 +178,8 @@ for fn in ("bench_vitl14.json", "bench_ksweep.json", "bench_f32.json", "bench_f1
 bad = False
 for fn in ("gemm_timeline.txt", "graph_phases.txt", "ubench_dma.txt", "per_layer_probe.txt", "bench_gemm.txt", "cu_mask_probe.txt",
            "attn_timeline.txt", "attn_bwd_timeline.txt", "half_batch_probe.txt", "gemm_ws_timeline.txt", "bench_gemm_ws.txt", "bench_text_attn.txt",
-           "trace_ncls1000.txt", "attn_variants.txt", "ab_round5_path_vs_round6.txt", "bench_gemm_t1k.txt"):
+           "trace_ncls1000.txt", "attn_variants.txt", "ab_round5_path_vs_round6.txt", "bench_gemm_t1k.txt", "bench_head.txt",
+           "ab_head_ncls1000.txt"):
     src = os.path.join(raw, fn)
     if os.path.exists(src):
         txt = "".join(l for l in open(src) if "amdgpu.ids" not in l)
