@@ -1,8 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c27
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/c27/pytest.txt
-RPO_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_ops.py -m gpu -q -k "joint_backward or mlp_fused or split_row or persistent_backward or pair or chain" 2>&1 | tail -3 > gpurun_out/c27/pytest_exp.txt
-timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 > gpurun_out/c27/smoke.txt
-QUICK=1 bash tools/collect_profiles.sh > gpurun_out/c27/collect.log 2>&1
-echo "collect rc=$?" >> gpurun_out/c27/collect.log
-cat gpurun_out/c27/pytest.txt gpurun_out/c27/pytest_exp.txt gpurun_out/c27/smoke.txt; tail -3 gpurun_out/c27/collect.log
+O=gpurun_out/c28; mkdir -p $O
+timeout 600 python tools/stress_determinism.py > $O/stress.txt 2>&1
+timeout 400 python bench.py > $O/bench_final.json 2> $O/bench_final.err
+timeout 400 python bench.py --n-cls 1000 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_ncls1000_final.json 2>> $O/bench_final.err
+tail -5 $O/stress.txt; cat $O/bench_final.json | cut -c1-400
