@@ -955,7 +955,9 @@ def test_text_attn_fwd_bwd(mode, lens, Kr):
                                      # the matrix-pipe path (C > 128) at the reference's ImageNet size and just past the fused path's 128
                                      (32, 1000, 24, 512), (2, 129, 1, 768),
                                      # ... whose kernels tile images and classes by 32: ragged tiles on both sides, odd pair counts
-                                     (40, 397, 24, 512), (33, 131, 3, 64)])
+                                     (40, 397, 24, 512), (33, 131, 3, 64),
+                                     # above 128 classes with a width the matrix-pipe kernels do not take: the three-launch path
+                                     (3, 150, 2, 100)])
 def test_head_fwd_bwd(B, C, K, e):
     o = ops()
     i_f, t_f = rnd((B, K, e), 31), rnd((C, K, e), 32)
