@@ -555,7 +555,7 @@ def test_many_classes_k24_against_oracle(n_cls, act):
     """K = 24 prompts over 100 / 397 / 1000 classes (the reference trains RPO on ImageNet's 1000: the text tower is then
     24 000 prompt rows, 2.3x the image tower's FLOPs -- the inverse of the Oxford-Pets bench): loss, both prompt gradients
     and the eval logits against the dense CPU oracle at depth 1, in every storage mode, through the kernels the engine
-    selects at that size (rpo_gemm_nt's wide tiles from 2048 rows on, the three-launch head, 8000 attention waves)."""
+    selects at that size (rpo_gemm_nt's wide tiles from 2048 rows on, the head on the fp32 matrix pipe, 8000 attention waves)."""
     from rpo_amd.custom_clip import CustomCLIP
     cfg, toks, sd, prm, image, label, o_loss, o_logits, gt, gi = _edge_oracle(24, MANY_CLASS_LENS[n_cls], 2, 1, 5, 13)
     m = CustomCLIP(cfg, sd, toks, "cuda:0", act, max_batch=2, prompts=prm)
